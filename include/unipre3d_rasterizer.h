@@ -1,0 +1,132 @@
+/*
+ * unipre3d_rasterizer.h -- C-ABI of the MI355X (gfx950) differentiable Gaussian-splat rasterizer.
+ *
+ * Drop-in boundary for the operator UniPre3D imports at gaussian_renderer/__init__.py:8
+ * (`from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer`)
+ * and calls at gaussian_renderer/__init__.py:45-61 (settings) and :89-97 (keyword call).
+ * The third-party extension behind that import exposes three native operations
+ * ([UPSTREAM-RECALL]):
+ *     rasterize_gaussians            -> u3d_rasterize_forward
+ *     rasterize_gaussians_backward   -> u3d_rasterize_backward
+ *     mark_visible                   -> u3d_mark_visible
+ * Here they are plain `extern "C"` functions over raw DEVICE pointers, sizes and a HIP stream;
+ * no torch types.  All tensors are contiguous fp32 (row-major), matrices are 4x4 row-major and
+ * stored for ROW-vector use (p_view = [p,1] * viewmatrix), exactly as the reference's datasets
+ * produce them (dataset/shapenet.py:305-320).
+ *
+ * One call renders `n_items * views_per_item` views: view v uses Gaussian set v / views_per_item.
+ * The reference's per-view operator is the special case n_items = views_per_item = 1; the batched
+ * form replaces the B x V Python loop of train_network.py:418-446 with one launch
+ * sequence.  Nothing here allocates, frees or synchronises: scratch is caller-provided (sizes from
+ * u3d_scratch_query), kernels are enqueued on `stream`, and -- unlike the original operator, which
+ * copies `num_rendered` back to the host on every forward -- there is no device->host copy.
+ *
+ * Ownership: every pointer is borrowed for the duration of the enqueued work.  The three forward
+ * scratch buffers must be kept unmodified until the matching backward has run.  Not re-entrant per
+ * scratch set.  Return value: U3D_OK or an error code (u3d_error_string); with U3D_FLAG_DEBUG the
+ * call also synchronises the stream and reports asynchronous kernel faults.
+ */
+#ifndef UNIPRE3D_RASTERIZER_H
+#define UNIPRE3D_RASTERIZER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define U3D_ABI_VERSION 1
+
+/* flags (fields 11-13 of GaussianRasterizationSettings, gaussian_renderer/__init__.py:56-58) */
+#define U3D_FLAG_PREFILTERED 1   /* accepted, no effect: culled points are dropped either way */
+#define U3D_FLAG_ANTIALIASING 2  /* opacity *= sqrt(max(2.5e-5, det(cov)/det(cov+0.3 I))) */
+#define U3D_FLAG_DEBUG 4         /* synchronise + check after the launch sequence */
+#define U3D_FLAG_EXACT_AA_GRAD 8 /* exact derivative of the anti-aliasing factor (DEV(vi)) */
+
+#define U3D_OK 0
+#define U3D_ERR_INVALID_ARGUMENT 1
+#define U3D_ERR_UNSUPPORTED 2
+#define U3D_ERR_LAUNCH 3
+#define U3D_ERR_NO_DEVICE 4
+
+typedef struct u3d_raster_desc {
+  int32_t n_items;        /* independent Gaussian sets (objects / scenes) in this call        */
+  int32_t views_per_item; /* cameras per set; n_views = n_items * views_per_item               */
+  int32_t P;              /* Gaussians per set                                                 */
+  int32_t image_height;   /* settings field 1                                                  */
+  int32_t image_width;    /* settings field 2                                                  */
+  float tanfovx;          /* settings field 3                                                  */
+  float tanfovy;          /* settings field 4                                                  */
+  float scale_modifier;   /* settings field 6                                                  */
+  int32_t sh_degree;      /* settings field 9: active SH degree D in 0..3                      */
+  int32_t sh_coeffs;      /* M = shs.shape[1] >= (D+1)^2; 0 when colors_precomp is used        */
+  int32_t flags;          /* U3D_FLAG_*                                                        */
+} u3d_raster_desc;
+
+typedef struct u3d_scratch_sizes {
+  size_t geom_bytes;     /* per (view, Gaussian) projected state  ("geomBuffer")              */
+  size_t binning_bytes;  /* depth-sorted ids / tile rects / sort temporaries ("binningBuffer") */
+  size_t image_bytes;    /* per-pixel final transmittance + last contributor ("imgBuffer")    */
+  size_t backward_bytes; /* per (view, Gaussian) screen-space gradient accumulators           */
+  size_t num_rendered_offset; /* byte offset inside geom of uint32 num_rendered[n_views]      */
+} u3d_scratch_sizes;
+
+int u3d_abi_version(void);
+const char* u3d_error_string(int code);
+
+/* Sizes of the caller-allocated scratch buffers for `desc` (pure host arithmetic). */
+int u3d_scratch_query(const u3d_raster_desc* desc, u3d_scratch_sizes* out);
+
+/*
+ * Forward: replaces `_C.rasterize_gaussians` behind gaussian_renderer/__init__.py:89-97.
+ *   bg              [3]
+ *   means3D         [n_items][P][3]
+ *   shs             [n_items][P][M][3]   or NULL  (exactly one of shs / colors_precomp)
+ *   colors_precomp  [n_items][P][3]      or NULL
+ *   opacities       [n_items][P]
+ *   scales          [n_items][P][3], rotations [n_items][P][4] (r,x,y,z; NOT normalised here)
+ *   cov3D_precomp   [n_items][P][6]      or NULL  (exactly one of scales+rotations / cov3D_precomp)
+ *   viewmatrix, projmatrix [n_views][16]; campos [n_views][3]
+ * outputs
+ *   out_color       [n_views][3][H][W]
+ *   out_invdepth    [n_views][1][H][W]   or NULL
+ *   radii           [n_views][P] int32   (0 = culled / off-screen)
+ */
+int u3d_rasterize_forward(const u3d_raster_desc* desc, const float* bg, const float* means3D, const float* shs,
+                          const float* colors_precomp, const float* opacities, const float* scales,
+                          const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                          const float* projmatrix, const float* campos, float* out_color, float* out_invdepth,
+                          int32_t* radii, void* geom, void* binning, void* image, void* stream);
+
+/*
+ * Backward: replaces `_C.rasterize_gaussians_backward` (triggered by loss.backward(),
+ * train_network.py:333).  Inputs as in forward plus the forward's radii/scratch and
+ *   dL_dcolor     [n_views][3][H][W]
+ *   dL_dinvdepth  [n_views][1][H][W] or NULL (treated as zeros; the reference drops that output)
+ * outputs (written, not accumulated; per set, summed over that set's views)
+ *   dL_dmeans3D [n_items][P][3], dL_dopacity [n_items][P],
+ *   dL_dshs [n_items][P][M][3] (NULL iff shs NULL), dL_dcolors [n_items][P][3] (may be NULL),
+ *   dL_dscales [n_items][P][3], dL_drotations [n_items][P][4] (NULL iff scales NULL),
+ *   dL_dcov3D [n_items][P][6] (may be NULL),
+ *   dL_dmeans2D [n_views][P][3] (may be NULL): screen-space gradient, the `viewspace_points` sink of
+ *                                               gaussian_renderer/__init__.py:29.
+ *   backward_scratch: backward_bytes; zeroed by the call.
+ */
+int u3d_rasterize_backward(const u3d_raster_desc* desc, const float* bg, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                           const float* projmatrix, const float* campos, const int32_t* radii,
+                           const float* dL_dcolor, const float* dL_dinvdepth, const void* geom,
+                           const void* binning, const void* image, void* backward_scratch, float* dL_dmeans3D,
+                           float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors, float* dL_dopacity,
+                           float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* stream);
+
+/* Frustum test only: replaces `_C.mark_visible` (no caller in the reference tree). present[P] = z_view > 0.2 */
+int u3d_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIPRE3D_RASTERIZER_H */

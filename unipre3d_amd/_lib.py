@@ -1,0 +1,86 @@
+"""ctypes binding of libunipre3d_rasterizer.so (the C-ABI declared in include/unipre3d_rasterizer.h).
+
+The product path has NO CPU or PyTorch fallback: if the HIP library is missing or cannot be loaded,
+`load()` raises.  `import torch` must precede the dlopen so that the library's libamdhip64.so.7
+dependency resolves to the HIP runtime PyTorch-ROCm already loaded (one runtime per process, so torch's
+streams and device pointers are valid inside the library).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must be imported before the library is opened, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libunipre3d_rasterizer.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+FLAG_PREFILTERED, FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_EXACT_AA_GRAD = 1, 2, 4, 8
+
+EXPORTS = ("u3d_abi_version", "u3d_error_string", "u3d_scratch_query", "u3d_rasterize_forward",
+           "u3d_rasterize_backward", "u3d_mark_visible")
+
+
+class RasterDesc(ctypes.Structure):
+    _fields_ = [("n_items", ctypes.c_int32), ("views_per_item", ctypes.c_int32), ("P", ctypes.c_int32),
+                ("image_height", ctypes.c_int32), ("image_width", ctypes.c_int32), ("tanfovx", ctypes.c_float),
+                ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float), ("sh_degree", ctypes.c_int32),
+                ("sh_coeffs", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+class ScratchSizes(ctypes.Structure):
+    _fields_ = [("geom_bytes", ctypes.c_size_t), ("binning_bytes", ctypes.c_size_t), ("image_bytes", ctypes.c_size_t),
+                ("backward_bytes", ctypes.c_size_t), ("num_rendered_offset", ctypes.c_size_t)]
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc build of libunipre3d_rasterizer.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if verbose:
+        print(res.stdout[-2000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the MI355X rasterizer has no fallback path. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C unipre3d_amd/csrc`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32 = ctypes.c_void_p, ctypes.c_int32
+    lib.u3d_abi_version.restype = ctypes.c_int
+    lib.u3d_error_string.restype = ctypes.c_char_p
+    lib.u3d_error_string.argtypes = [ctypes.c_int]
+    lib.u3d_scratch_query.restype = ctypes.c_int
+    lib.u3d_scratch_query.argtypes = [ctypes.POINTER(RasterDesc), ctypes.POINTER(ScratchSizes)]
+    lib.u3d_rasterize_forward.restype = ctypes.c_int
+    lib.u3d_rasterize_forward.argtypes = [ctypes.POINTER(RasterDesc)] + [vp] * 18
+    lib.u3d_rasterize_backward.restype = ctypes.c_int
+    lib.u3d_rasterize_backward.argtypes = [ctypes.POINTER(RasterDesc)] + [vp] * 27
+    lib.u3d_mark_visible.restype = ctypes.c_int
+    lib.u3d_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
+    if lib.u3d_abi_version() != 1:
+        raise RuntimeError("libunipre3d_rasterizer.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError(f"{what} failed: {load().u3d_error_string(code).decode()} (code {code})")
+
+
+def ptr(t) -> ctypes.c_void_p:
+    """Device pointer of a tensor (None -> NULL)."""
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())

@@ -1,0 +1,122 @@
+// Internal definitions shared by the gfx950 kernels and the C-ABI (not part of the public boundary).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "unipre3d_rasterizer.h"
+
+#define U3D_TILE 16
+#define U3D_BLOCK 256       // threads per workgroup = 4 wave64 = one 16x16 tile
+#define U3D_WAVE 64
+#define U3D_NACC 10         // mean2D.xy, conic(a, b/2, c), opacity, rgb, invdepth
+#define U3D_LDS_SORT_MAX 4096  // largest per-view P sorted by one workgroup in LDS
+
+// Per-call view of the carved scratch buffers (device pointers; built on the host).
+struct U3DBuffers {
+  // geom: index g = view * P + i
+  float* depth;       // [NV*P]   view-space z (sort key); 0 for culled
+  float2* xy;         // [NV*P]   pixel-space mean
+  float4* conic_op;   // [NV*P]   conic a,b,c ; opacity * aa
+  float4* rgbd;       // [NV*P]   clamped colour, w = depth
+  uint2* rect;        // [NV*P]   x: xmin | ymin<<16 ; y: xmax | ymax<<16   (tile units)
+  uint32_t* clamped;  // [NV*P]   bit c set: colour channel c clamped at 0
+  uint32_t* num_rendered;  // [NV] sum of tiles touched (statistics only)
+  // binning
+  uint32_t* sorted_id;   // [NV*P] Gaussian index (within the set) in front-to-back order
+  uint2* sorted_rect;    // [NV*P] rect of sorted_id[k]
+  uint32_t* n_vis;       // [NV]   number of entries of the sorted list that are on screen
+  uint32_t* sort_keys[2];  // [NV*P] x2  radix ping-pong (large P only)
+  uint32_t* sort_vals[2];  // [NV*P] x2
+  uint32_t* sort_hist;     // radix histograms
+  // image
+  float* final_T;        // [NV*H*W]
+  uint32_t* n_contrib;   // [NV*H*W]  sorted position + 1 of the last contributor
+};
+
+struct U3DLayout {
+  size_t geom_bytes, binning_bytes, image_bytes, backward_bytes, num_rendered_offset;
+};
+
+static inline size_t u3d_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// single source of truth for carving; base pointers may be null when only sizes are wanted
+static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* binning, void* image, U3DBuffers* b) {
+  const size_t NV = (size_t)d.n_items * d.views_per_item, NG = NV * (size_t)d.P;
+  const size_t NP = NV * (size_t)d.image_height * d.image_width;
+  U3DLayout L{};
+  size_t o = 0;
+  char* g = (char*)geom;
+#define CARVE(base, field, type, count)        \
+  do {                                         \
+    if (b) b->field = (type*)(base + o);       \
+    o += u3d_align(sizeof(type) * (count));    \
+  } while (0)
+  CARVE(g, depth, float, NG);
+  CARVE(g, xy, float2, NG);
+  CARVE(g, conic_op, float4, NG);
+  CARVE(g, rgbd, float4, NG);
+  CARVE(g, rect, uint2, NG);
+  CARVE(g, clamped, uint32_t, NG);
+  L.num_rendered_offset = o;
+  CARVE(g, num_rendered, uint32_t, NV);
+  L.geom_bytes = o > 0 ? o : 256;
+  o = 0;
+  char* bn = (char*)binning;
+  CARVE(bn, sorted_id, uint32_t, NG);
+  CARVE(bn, sorted_rect, uint2, NG);
+  CARVE(bn, n_vis, uint32_t, NV);
+  if (d.P > U3D_LDS_SORT_MAX) {
+    CARVE(bn, sort_keys[0], uint32_t, NG);
+    CARVE(bn, sort_keys[1], uint32_t, NG);
+    CARVE(bn, sort_vals[0], uint32_t, NG);
+    CARVE(bn, sort_vals[1], uint32_t, NG);
+    const size_t nblk = ((size_t)d.P + 4095) / 4096;
+    CARVE(bn, sort_hist, uint32_t, NV * 256 * nblk);
+  } else if (b) {
+    b->sort_keys[0] = b->sort_keys[1] = b->sort_vals[0] = b->sort_vals[1] = b->sort_hist = nullptr;
+  }
+  L.binning_bytes = o > 0 ? o : 256;
+  o = 0;
+  char* im = (char*)image;
+  CARVE(im, final_T, float, NP);
+  CARVE(im, n_contrib, uint32_t, NP);
+  L.image_bytes = o > 0 ? o : 256;
+#undef CARVE
+  L.backward_bytes = u3d_align(sizeof(float) * U3D_NACC * (NG > 0 ? NG : 1));
+  return L;
+}
+
+// launchers (one per translation unit)
+void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* means3D, const float* shs,
+                               const float* colors_precomp, const float* opacities, const float* scales,
+                               const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                               const float* projmatrix, const float* campos, int32_t* radii, hipStream_t s);
+void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* means3D, const float* shs,
+                               const float* colors_precomp, const float* opacities, const float* scales,
+                               const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                               const float* projmatrix, const float* campos, const int32_t* radii,
+                               const float* acc, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                               float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                               float* dL_dcov3D, hipStream_t s);
+void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const int32_t* radii, hipStream_t s);
+void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,
+                           float* out_invdepth, hipStream_t s);
+void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, const float* dL_dcolor,
+                           const float* dL_dinvdepth, float* acc, hipStream_t s);
+
+#ifdef __HIPCC__
+// ---- device helpers -------------------------------------------------------------------------
+// Workgroup -> logical id remap so that consecutive logical ids (tiles of one view, which share
+// that view's sorted Gaussian state) stay on ONE XCD's L2.  Hardware places workgroup b on XCD
+// b % 8 (observed, speed only); this bijection sends logical ids [x*q .. ) to XCD x.
+__device__ __forceinline__ uint32_t u3d_xcd_remap(uint32_t bid, uint32_t nblocks) {
+  const uint32_t q = nblocks >> 3, r = nblocks & 7u;
+  const uint32_t xcd = bid & 7u, k = bid >> 3;
+  const uint32_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + k;
+}
+
+__device__ __forceinline__ uint32_t u3d_lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+#endif

@@ -1,0 +1,510 @@
+// Per-Gaussian projection kernels for gfx950: forward (3D -> 2D mean, EWA covariance, conic, radius,
+// tile rectangle, SH colour) and the matching backward (conic/mean2D/colour gradients -> mean3D,
+// scale, rotation, opacity, SH).  Semantics: SURVEY.md R4 steps 1-7 and R5/R6; restated on the CPU in
+// oracle/raster_oracle.c.  One thread per (view, Gaussian) forward; one thread per (set, Gaussian)
+// backward, looping over that set's views so the per-set gradient needs no atomics.
+#include "u3d_common.h"
+
+namespace {
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+struct Cam {
+  float V[16], Pm[16], pos[3];
+};
+
+__device__ __forceinline__ void load_cam(Cam& c, const float* __restrict__ view, const float* __restrict__ proj,
+                                         const float* __restrict__ campos, int v) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { c.V[k] = view[v * 16 + k]; c.Pm[k] = proj[v * 16 + k]; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) c.pos[k] = campos[v * 3 + k];
+}
+
+__device__ __forceinline__ void quat_to_R(const float q[4], float R[9]) {
+  const float r = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
+  R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+  R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = (R S)(R S)^T, upper triangle
+__device__ __forceinline__ void cov3d_from_scale_rot(const float s[3], float mod, const float q[4], float c6[6]) {
+  float R[9], M[9];
+  quat_to_R(q, R);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) M[i * 3 + k] = R[i * 3 + k] * (mod * s[k]);
+  c6[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+  c6[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+  c6[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+  c6[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+  c6[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+  c6[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+}
+
+struct Ewa {
+  float t[3];  // view-space point, x/y clamped
+  float xmask, ymask;
+  float M2[6];  // J * W (2x3)
+  float fx, fy;
+};
+
+__device__ __forceinline__ void ewa_setup(Ewa& e, const float p[3], const Cam& c, float fx, float fy, float tanx,
+                                          float tany) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) e.t[j] = c.V[j] * p[0] + c.V[4 + j] * p[1] + c.V[8 + j] * p[2] + c.V[12 + j];
+  const float limx = 1.3f * tanx, limy = 1.3f * tany;
+  const float txtz = e.t[0] / e.t[2], tytz = e.t[1] / e.t[2];
+  e.xmask = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+  e.ymask = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+  e.t[0] = fminf(limx, fmaxf(-limx, txtz)) * e.t[2];
+  e.t[1] = fminf(limy, fmaxf(-limy, tytz)) * e.t[2];
+  e.fx = fx; e.fy = fy;
+  const float tz = e.t[2];
+  const float J00 = fx / tz, J02 = -(fx * e.t[0]) / (tz * tz), J11 = fy / tz, J12 = -(fy * e.t[1]) / (tz * tz);
+  // W[j][i] = V[i*4+j]
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    e.M2[i] = J00 * c.V[i * 4 + 0] + J02 * c.V[i * 4 + 2];
+    e.M2[3 + i] = J11 * c.V[i * 4 + 1] + J12 * c.V[i * 4 + 2];
+  }
+}
+
+__device__ __forceinline__ void cov2d(const Ewa& e, const float c6[6], float abc[3]) {
+  const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+  float MS[6];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) MS[k * 3 + j] = e.M2[k * 3] * S[j] + e.M2[k * 3 + 1] * S[3 + j] + e.M2[k * 3 + 2] * S[6 + j];
+  abc[0] = MS[0] * e.M2[0] + MS[1] * e.M2[1] + MS[2] * e.M2[2];
+  abc[1] = MS[0] * e.M2[3] + MS[1] * e.M2[4] + MS[2] * e.M2[5];
+  abc[2] = MS[3] * e.M2[3] + MS[4] * e.M2[4] + MS[5] * e.M2[5];
+}
+
+template <int D>
+__device__ __forceinline__ void sh_to_rgb(const float* __restrict__ sh /* [M][3] */, const float dir[3], float rgb[3],
+                                          uint32_t& clamp_bits) {
+  const float x = dir[0], y = dir[1], z = dir[2];
+  clamp_bits = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float res = SH_C0 * sh[c];
+    if (D > 0) {
+      res = res - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
+      if (D > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        res = res + SH_C2[0] * xy * sh[12 + c] + SH_C2[1] * yz * sh[15 + c] + SH_C2[2] * (2.f * zz - xx - yy) * sh[18 + c] +
+              SH_C2[3] * xz * sh[21 + c] + SH_C2[4] * (xx - yy) * sh[24 + c];
+        if (D > 2) {
+          res = res + SH_C3[0] * y * (3.f * xx - yy) * sh[27 + c] + SH_C3[1] * xy * z * sh[30 + c] +
+                SH_C3[2] * y * (4.f * zz - xx - yy) * sh[33 + c] + SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[36 + c] +
+                SH_C3[4] * x * (4.f * zz - xx - yy) * sh[39 + c] + SH_C3[5] * z * (xx - yy) * sh[42 + c] +
+                SH_C3[6] * x * (xx - 3.f * yy) * sh[45 + c];
+        }
+      }
+    }
+    res += 0.5f;
+    if (res < 0.f) clamp_bits |= 1u << c;
+    rgb[c] = fmaxf(res, 0.f);
+  }
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
+    int P, int vpi, int M, int H, int W, float tanx, float tany, float mod, int flags, const float* __restrict__ means3D,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+    const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
+    int32_t* __restrict__ radii, float* __restrict__ depth, float2* __restrict__ xy, float4* __restrict__ conic_op,
+    float4* __restrict__ rgbd, uint2* __restrict__ rect, uint32_t* __restrict__ clamped,
+    uint32_t* __restrict__ num_rendered) {
+  const int view = blockIdx.y;
+  const int i = blockIdx.x * U3D_BLOCK + threadIdx.x;
+  uint32_t touched = 0;
+  if (i < P) {
+    const size_t g = (size_t)view * P + i;
+    const size_t gi = (size_t)(view / vpi) * P + i;
+    Cam cam;
+    load_cam(cam, viewmatrix, projmatrix, campos, view);
+    const float p[3] = {means3D[gi * 3], means3D[gi * 3 + 1], means3D[gi * 3 + 2]};
+    int radius = 0;
+    float zv = cam.V[2] * p[0] + cam.V[6] * p[1] + cam.V[10] * p[2] + cam.V[14];
+    float2 pix = make_float2(0.f, 0.f);
+    float4 co = make_float4(0.f, 0.f, 0.f, 0.f), col = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 rc = make_uint2(0u, 0u);
+    uint32_t cb = 0;
+    if (zv > 0.2f) {
+      float hom[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hom[j] = cam.Pm[j] * p[0] + cam.Pm[4 + j] * p[1] + cam.Pm[8 + j] * p[2] + cam.Pm[12 + j];
+      const float p_w = 1.0f / (hom[3] + 0.0000001f);
+      float c6[6];
+      if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[gi * 6 + k];
+      } else {
+        const float s[3] = {scales[gi * 3], scales[gi * 3 + 1], scales[gi * 3 + 2]};
+        const float q[4] = {rotations[gi * 4], rotations[gi * 4 + 1], rotations[gi * 4 + 2], rotations[gi * 4 + 3]};
+        cov3d_from_scale_rot(s, mod, q, c6);
+      }
+      const float fx = (float)W / (2.f * tanx), fy = (float)H / (2.f * tany);
+      Ewa e;
+      ewa_setup(e, p, cam, fx, fy, tanx, tany);
+      float abc[3];
+      cov2d(e, c6, abc);
+      const float det0 = abc[0] * abc[2] - abc[1] * abc[1];
+      abc[0] += 0.3f; abc[2] += 0.3f;
+      const float det = abc[0] * abc[2] - abc[1] * abc[1];
+      float aa = 1.f;
+      if (flags & U3D_FLAG_ANTIALIASING) aa = sqrtf(fmaxf(0.000025f, det0 / det));
+      if (det != 0.f) {
+        const float det_inv = 1.f / det;
+        const float mid = 0.5f * (abc[0] + abc[2]);
+        const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float my_radius = ceilf(3.f * sqrtf(fmaxf(mid + sq, mid - sq)));
+        const float px = ((hom[0] * p_w + 1.f) * (float)W - 1.f) * 0.5f;
+        const float py = ((hom[1] * p_w + 1.f) * (float)H - 1.f) * 0.5f;
+        const int gx = (W + U3D_TILE - 1) / U3D_TILE, gy = (H + U3D_TILE - 1) / U3D_TILE;
+        const int r = (int)my_radius;
+        const int x0 = clampi((int)((px - (float)r) / (float)U3D_TILE), 0, gx);
+        const int y0 = clampi((int)((py - (float)r) / (float)U3D_TILE), 0, gy);
+        const int x1 = clampi((int)((px + (float)r + (float)(U3D_TILE - 1)) / (float)U3D_TILE), 0, gx);
+        const int y1 = clampi((int)((py + (float)r + (float)(U3D_TILE - 1)) / (float)U3D_TILE), 0, gy);
+        const int nt = (x1 - x0) * (y1 - y0);
+        if (nt > 0) {
+          float rgb[3];
+          if (colors_precomp) {
+            rgb[0] = colors_precomp[gi * 3]; rgb[1] = colors_precomp[gi * 3 + 1]; rgb[2] = colors_precomp[gi * 3 + 2];
+          } else {
+            float dir[3] = {p[0] - cam.pos[0], p[1] - cam.pos[1], p[2] - cam.pos[2]};
+            const float inv = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+            dir[0] *= inv; dir[1] *= inv; dir[2] *= inv;
+            sh_to_rgb<D>(shs + gi * (size_t)M * 3, dir, rgb, cb);
+          }
+          radius = r;
+          touched = (uint32_t)nt;
+          pix = make_float2(px, py);
+          co = make_float4(abc[2] * det_inv, -abc[1] * det_inv, abc[0] * det_inv, opacities[gi] * aa);
+          col = make_float4(rgb[0], rgb[1], rgb[2], zv);
+          rc = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
+        }
+      }
+    }
+    radii[g] = radius;
+    depth[g] = radius > 0 ? zv : 0.f;
+    xy[g] = pix;
+    conic_op[g] = co;
+    rgbd[g] = col;
+    rect[g] = rc;
+    clamped[g] = cb;
+  }
+  // statistics: num_rendered[view] += sum(tiles touched)   (wave reduce, one atomic per wave)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) touched += __shfl_xor(touched, o);
+  if ((threadIdx.x & 63) == 0 && touched) atomicAdd(&num_rendered[view], touched);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
+    int P, int vpi, int M, int H, int W, float tanx, float tany, float mod, int flags, size_t NG,
+    const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ opacities,
+    const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
+    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const float* __restrict__ acc,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs,
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D) {
+  const int item = blockIdx.y;
+  const int i = blockIdx.x * U3D_BLOCK + threadIdx.x;
+  if (i >= P) return;
+  const size_t gi = (size_t)item * P + i;
+  const float p[3] = {means3D[gi * 3], means3D[gi * 3 + 1], means3D[gi * 3 + 2]};
+  float c6[6];
+  float s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  if (cov3D_precomp) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[gi * 6 + k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = scales[gi * 3 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = rotations[gi * 4 + k];
+    cov3d_from_scale_rot(s, mod, q, c6);
+  }
+  const float op_in = opacities[gi];
+  constexpr int K = (D + 1) * (D + 1);
+  float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
+  float dsh[K * 3];
+#pragma unroll
+  for (int k = 0; k < K * 3; ++k) dsh[k] = 0.f;
+  const float fx = (float)W / (2.f * tanx), fy = (float)H / (2.f * tany);
+
+  for (int vk = 0; vk < vpi; ++vk) {
+    const int view = item * vpi + vk;
+    const size_t g = (size_t)view * P + i;
+    const bool live = radii[g] > 0;
+    float a[U3D_NACC];
+#pragma unroll
+    for (int k = 0; k < U3D_NACC; ++k) a[k] = live ? acc[(size_t)k * NG + g] : 0.f;
+    if (dL_dmeans2D) {
+      dL_dmeans2D[g * 3] = a[0]; dL_dmeans2D[g * 3 + 1] = a[1]; dL_dmeans2D[g * 3 + 2] = 0.f;
+    }
+    if (!live) continue;
+    Cam cam;
+    load_cam(cam, viewmatrix, projmatrix, campos, view);
+    Ewa e;
+    ewa_setup(e, p, cam, fx, fy, tanx, tany);
+    float abc[3];
+    cov2d(e, c6, abc);
+    float c_xx = abc[0], c_xy = abc[1], c_yy = abc[2];
+    const float x0 = c_xx, y0 = c_yy, h_var = 0.3f;
+    float d_inside_root = 0.f;
+    float dop_v = a[5];
+    if (flags & U3D_FLAG_ANTIALIASING) {
+      const float det_cov = c_xx * c_yy - c_xy * c_xy;
+      c_xx += h_var; c_yy += h_var;
+      const float det_plus = c_xx * c_yy - c_xy * c_xy;
+      const float ratio = det_cov / det_plus;
+      const float hs = sqrtf(fmaxf(0.000025f, ratio));
+      const float d_hs = dop_v * op_in;
+      dop_v = dop_v * hs;
+      d_inside_root = ratio <= 0.000025f ? 0.f : d_hs / (2.f * hs);
+    } else {
+      c_xx += h_var; c_yy += h_var;
+    }
+    dop += dop_v;
+    float dcxx = 0.f, dcxy = 0.f, dcyy = 0.f;
+    if (flags & U3D_FLAG_ANTIALIASING) {
+      const bool exact = (flags & U3D_FLAG_EXACT_AA_GRAD) != 0;
+      const float x = exact ? x0 : c_xx, y = exact ? y0 : c_yy, z = c_xy, w = h_var;
+      const float dn = w * w + w * (x + y) + x * y - z * z;
+      const float denom_f = d_inside_root / (dn * dn);
+      dcxx = w * (w * y + y * y + z * z) * denom_f;
+      dcyy = w * (w * x + x * x + z * z) * denom_f;
+      dcxy = -2.f * w * z * (w + x + y) * denom_f;
+    }
+    const float dA = a[2], dBh = a[3], dC = a[4];
+    const float denom = c_xx * c_yy - c_xy * c_xy;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float dt[3] = {0.f, 0.f, 0.f};
+    if (denom2inv != 0.f) {
+      dcxx += denom2inv * (-c_yy * c_yy * dA + 2.f * c_xy * c_yy * dBh + (denom - c_xx * c_yy) * dC);
+      dcyy += denom2inv * (-c_xx * c_xx * dC + 2.f * c_xx * c_xy * dBh + (denom - c_xx * c_yy) * dA);
+      dcxy += denom2inv * 2.f * (c_xy * c_yy * dA - (denom + 2.f * c_xy * c_xy) * dBh + c_xx * c_xy * dC);
+      const float Gc[4] = {dcxx, 0.5f * dcxy, 0.5f * dcxy, dcyy};
+      float GM[6];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) GM[k * 3 + j] = Gc[k * 2] * e.M2[j] + Gc[k * 2 + 1] * e.M2[3 + j];
+      // dSigma = M2^T Gc M2  (stored upper triangle: off-diagonals carry both symmetric entries)
+      dcov[0] += e.M2[0] * GM[0] + e.M2[3] * GM[3];
+      dcov[3] += e.M2[1] * GM[1] + e.M2[4] * GM[4];
+      dcov[5] += e.M2[2] * GM[2] + e.M2[5] * GM[5];
+      dcov[1] += 2.f * (e.M2[0] * GM[1] + e.M2[3] * GM[4]);
+      dcov[2] += 2.f * (e.M2[0] * GM[2] + e.M2[3] * GM[5]);
+      dcov[4] += 2.f * (e.M2[1] * GM[2] + e.M2[4] * GM[5]);
+      // dM2 = 2 Gc M2 Sigma ; dJ = dM2 W^T
+      const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+      float dM2[6];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dM2[k * 3 + j] = 2.f * (GM[k * 3] * S[j] + GM[k * 3 + 1] * S[3 + j] + GM[k * 3 + 2] * S[6 + j]);
+      // dJ[k][l] = sum_m dM2[k][m] * W[l][m],  W[l][m] = V[m*4+l]
+      const float dJ00 = dM2[0] * cam.V[0] + dM2[1] * cam.V[4] + dM2[2] * cam.V[8];
+      const float dJ02 = dM2[0] * cam.V[2] + dM2[1] * cam.V[6] + dM2[2] * cam.V[10];
+      const float dJ11 = dM2[3] * cam.V[1] + dM2[4] * cam.V[5] + dM2[5] * cam.V[9];
+      const float dJ12 = dM2[3] * cam.V[2] + dM2[4] * cam.V[6] + dM2[5] * cam.V[10];
+      const float tz = 1.f / e.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+      dt[0] = e.xmask * -fx * tz2 * dJ02;
+      dt[1] = e.ymask * -fy * tz2 * dJ12;
+      dt[2] = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * e.t[0]) * tz3 * dJ02 + (2.f * fy * e.t[1]) * tz3 * dJ12;
+    }
+    dt[2] -= a[9] / (e.t[2] * e.t[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dmean[k] += cam.V[k * 4] * dt[0] + cam.V[k * 4 + 1] * dt[1] + cam.V[k * 4 + 2] * dt[2];
+    // screen-space mean
+    float hom[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hom[j] = cam.Pm[j] * p[0] + cam.Pm[4 + j] * p[1] + cam.Pm[8 + j] * p[2] + cam.Pm[12 + j];
+    const float m_w = 1.0f / (hom[3] + 0.0000001f);
+    const float mul1 = hom[0] * m_w * m_w, mul2 = hom[1] * m_w * m_w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      dmean[k] += (cam.Pm[k * 4] * m_w - cam.Pm[k * 4 + 3] * mul1) * a[0] + (cam.Pm[k * 4 + 1] * m_w - cam.Pm[k * 4 + 3] * mul2) * a[1];
+    dcol[0] += a[6]; dcol[1] += a[7]; dcol[2] += a[8];
+    if (shs) {
+      const float* sh = shs + gi * (size_t)M * 3;
+      const float dorig[3] = {p[0] - cam.pos[0], p[1] - cam.pos[1], p[2] - cam.pos[2]};
+      const float sum2 = dorig[0] * dorig[0] + dorig[1] * dorig[1] + dorig[2] * dorig[2];
+      const float inv = 1.f / sqrtf(sum2);
+      const float x = dorig[0] * inv, y = dorig[1] * inv, z = dorig[2] * inv;
+      const uint32_t cb = clamped[g];
+      float ddir[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float gr = (cb >> c) & 1u ? 0.f : a[6 + c];
+        dsh[c] += SH_C0 * gr;
+        float dx_ = 0.f, dy_ = 0.f, dz_ = 0.f;
+        if (D > 0) {
+          dsh[3 + c] += -SH_C1 * y * gr;
+          dsh[6 + c] += SH_C1 * z * gr;
+          dsh[9 + c] += -SH_C1 * x * gr;
+          dx_ = -SH_C1 * sh[9 + c]; dy_ = -SH_C1 * sh[3 + c]; dz_ = SH_C1 * sh[6 + c];
+          if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy_ = x * y, yz = y * z, xz = x * z;
+            dsh[12 + c] += SH_C2[0] * xy_ * gr;
+            dsh[15 + c] += SH_C2[1] * yz * gr;
+            dsh[18 + c] += SH_C2[2] * (2.f * zz - xx - yy) * gr;
+            dsh[21 + c] += SH_C2[3] * xz * gr;
+            dsh[24 + c] += SH_C2[4] * (xx - yy) * gr;
+            dx_ += SH_C2[0] * y * sh[12 + c] + SH_C2[2] * 2.f * -x * sh[18 + c] + SH_C2[3] * z * sh[21 + c] + SH_C2[4] * 2.f * x * sh[24 + c];
+            dy_ += SH_C2[0] * x * sh[12 + c] + SH_C2[1] * z * sh[15 + c] + SH_C2[2] * 2.f * -y * sh[18 + c] + SH_C2[4] * 2.f * -y * sh[24 + c];
+            dz_ += SH_C2[1] * y * sh[15 + c] + SH_C2[2] * 4.f * z * sh[18 + c] + SH_C2[3] * x * sh[21 + c];
+            if (D > 2) {
+              dsh[27 + c] += SH_C3[0] * y * (3.f * xx - yy) * gr;
+              dsh[30 + c] += SH_C3[1] * xy_ * z * gr;
+              dsh[33 + c] += SH_C3[2] * y * (4.f * zz - xx - yy) * gr;
+              dsh[36 + c] += SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * gr;
+              dsh[39 + c] += SH_C3[4] * x * (4.f * zz - xx - yy) * gr;
+              dsh[42 + c] += SH_C3[5] * z * (xx - yy) * gr;
+              dsh[45 + c] += SH_C3[6] * x * (xx - 3.f * yy) * gr;
+              dx_ += SH_C3[0] * sh[27 + c] * 6.f * xy_ + SH_C3[1] * sh[30 + c] * yz + SH_C3[2] * sh[33 + c] * -2.f * xy_ +
+                     SH_C3[3] * sh[36 + c] * -6.f * xz + SH_C3[4] * sh[39 + c] * (4.f * zz - 3.f * xx - yy) +
+                     SH_C3[5] * sh[42 + c] * 2.f * xz + SH_C3[6] * sh[45 + c] * 3.f * (xx - yy);
+              dy_ += SH_C3[0] * sh[27 + c] * 3.f * (xx - yy) + SH_C3[1] * sh[30 + c] * xz + SH_C3[2] * sh[33 + c] * (4.f * zz - xx - 3.f * yy) +
+                     SH_C3[3] * sh[36 + c] * -6.f * yz + SH_C3[4] * sh[39 + c] * -2.f * xy_ + SH_C3[5] * sh[42 + c] * -2.f * yz +
+                     SH_C3[6] * sh[45 + c] * -6.f * xy_;
+              dz_ += SH_C3[1] * sh[30 + c] * xy_ + SH_C3[2] * sh[33 + c] * 8.f * yz + SH_C3[3] * sh[36 + c] * 3.f * (2.f * zz - xx - yy) +
+                     SH_C3[4] * sh[39 + c] * 8.f * xz + SH_C3[5] * sh[42 + c] * (xx - yy);
+            }
+          }
+        }
+        ddir[0] += dx_ * gr; ddir[1] += dy_ * gr; ddir[2] += dz_ * gr;
+      }
+      const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+      dmean[0] += ((sum2 - dorig[0] * dorig[0]) * ddir[0] - dorig[1] * dorig[0] * ddir[1] - dorig[2] * dorig[0] * ddir[2]) * invsum32;
+      dmean[1] += (-dorig[0] * dorig[1] * ddir[0] + (sum2 - dorig[1] * dorig[1]) * ddir[1] - dorig[2] * dorig[1] * ddir[2]) * invsum32;
+      dmean[2] += (-dorig[0] * dorig[2] * ddir[0] - dorig[1] * dorig[2] * ddir[1] + (sum2 - dorig[2] * dorig[2]) * ddir[2]) * invsum32;
+    }
+  }
+
+  dL_dmeans3D[gi * 3] = dmean[0]; dL_dmeans3D[gi * 3 + 1] = dmean[1]; dL_dmeans3D[gi * 3 + 2] = dmean[2];
+  dL_dopacity[gi] = dop;
+  if (dL_dcolors) { dL_dcolors[gi * 3] = dcol[0]; dL_dcolors[gi * 3 + 1] = dcol[1]; dL_dcolors[gi * 3 + 2] = dcol[2]; }
+  if (dL_dcov3D) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov3D[gi * 6 + k] = dcov[k];
+  }
+  if (dL_dshs) {
+    float* o = dL_dshs + gi * (size_t)M * 3;
+#pragma unroll
+    for (int k = 0; k < K * 3; ++k) o[k] = dsh[k];
+    for (int k = K * 3; k < M * 3; ++k) o[k] = 0.f;
+  }
+  if (dL_dscales) {
+    // Sigma = Mx Mx^T, Mx = R diag(mod*s): exact derivative of the un-normalised quaternion polynomial
+    const float Gs[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
+                         0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
+    float R[9], Mx[9], sv[3];
+    quat_to_R(q, R);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sv[k] = mod * s[k];
+#pragma unroll
+    for (int r_ = 0; r_ < 3; ++r_)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Mx[r_ * 3 + k] = R[r_ * 3 + k] * sv[k];
+    float dR[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float ssum = 0.f;
+#pragma unroll
+      for (int r_ = 0; r_ < 3; ++r_) {
+        const float dM = 2.f * (Gs[r_ * 3] * Mx[k] + Gs[r_ * 3 + 1] * Mx[3 + k] + Gs[r_ * 3 + 2] * Mx[6 + k]);
+        ssum += dM * R[r_ * 3 + k];
+        dR[r_ * 3 + k] = dM * sv[k];
+      }
+      dL_dscales[gi * 3 + k] = mod * ssum;
+    }
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    dL_drotations[gi * 4 + 0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+    dL_drotations[gi * 4 + 1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
+    dL_drotations[gi * 4 + 2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
+    dL_drotations[gi * 4 + 3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+  }
+}
+
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ V,
+                                    uint8_t* __restrict__ present) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float z = V[2] * means3D[i * 3] + V[6] * means3D[i * 3 + 1] + V[10] * means3D[i * 3 + 2] + V[14];
+  present[i] = z > 0.2f ? 1 : 0;
+}
+
+}  // namespace
+
+void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* means3D, const float* shs,
+                               const float* colors_precomp, const float* opacities, const float* scales,
+                               const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                               const float* projmatrix, const float* campos, int32_t* radii, hipStream_t s) {
+  const int NV = d.n_items * d.views_per_item;
+  dim3 grid((d.P + U3D_BLOCK - 1) / U3D_BLOCK, NV), block(U3D_BLOCK);
+  const int D = shs ? d.sh_degree : 0;
+#define LAUNCH(DEG)                                                                                                   \
+  hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, 0, s, d.P, d.views_per_item, d.sh_coeffs, d.image_height, \
+                     d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, means3D, shs, colors_precomp,    \
+                     opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, radii, b.depth, b.xy, \
+                     b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered)
+  switch (D) {
+    case 0: LAUNCH(0); break;
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    default: LAUNCH(3); break;
+  }
+#undef LAUNCH
+}
+
+void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* means3D, const float* shs,
+                               const float* colors_precomp, const float* opacities, const float* scales,
+                               const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                               const float* projmatrix, const float* campos, const int32_t* radii, const float* acc,
+                               float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                               float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                               hipStream_t s) {
+  (void)colors_precomp;
+  const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
+  dim3 grid((d.P + U3D_BLOCK - 1) / U3D_BLOCK, d.n_items), block(U3D_BLOCK);
+  const int D = shs ? d.sh_degree : 0;
+#define LAUNCH(DEG)                                                                                                    \
+  hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, d.P, d.views_per_item, d.sh_coeffs, d.image_height, \
+                     d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, NG, means3D, shs, opacities, scales, \
+                     rotations, cov3D_precomp, viewmatrix, projmatrix, campos, radii, b.clamped, acc, dL_dmeans3D,     \
+                     dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D)
+  switch (D) {
+    case 0: LAUNCH(0); break;
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    default: LAUNCH(3); break;
+  }
+#undef LAUNCH
+}
+
+void u3d_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
+}

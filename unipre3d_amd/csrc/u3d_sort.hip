@@ -1,0 +1,213 @@
+// Front-to-back ordering: ONE depth sort per view (not one per tile instance).
+//
+// The original operator duplicates every Gaussian once per touched tile, sorts the R = sum(tiles
+// touched) 64-bit keys (tile << 32 | depth bits) with a stable radix sort and then finds per-tile
+// ranges.  Within a tile that order is "ascending depth bits, ties by ascending
+// Gaussian index".  Sorting the P Gaussians of a view once by (depth bits, index) and letting every
+// tile filter that list by its rectangle (u3d_render.hip) yields exactly the same per-tile sequence
+// while moving 12*P instead of 36*R bytes (R ~ P*T for the reference's large splats).
+//
+//  * P <= 4096: one workgroup per view, bitonic network on 64-bit keys (depth bits << 32 | index)
+//    entirely in LDS (32 KiB of the CU's 160 KiB).
+//  * larger P: 4-pass LSD radix sort (8-bit digits) on the depth bits with the index as payload;
+//    LSD passes are stable and the initial order is index order, so ties resolve by index.
+#include "u3d_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(1024) void depth_sort_lds_kernel(int P, int N, const float* __restrict__ depth,
+                                                              const int32_t* __restrict__ radii,
+                                                              const uint2* __restrict__ rect,
+                                                              uint32_t* __restrict__ sorted_id,
+                                                              uint2* __restrict__ sorted_rect,
+                                                              uint32_t* __restrict__ n_vis) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  const int view = blockIdx.x;
+  const size_t base = (size_t)view * P;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < N; i += nt) {
+    unsigned long long k = ~0ull;
+    if (i < P && radii[base + i] > 0) k = ((unsigned long long)__float_as_uint(depth[base + i]) << 32) | (uint32_t)i;
+    keys[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < N; i += nt) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], b = keys[ixj];
+          const bool asc = (i & k) == 0;
+          if ((a > b) == asc) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0 && keys[0] == ~0ull) n_vis[view] = 0;
+  for (int i = tid; i < N; i += nt) {
+    const unsigned long long k = keys[i];
+    if (k != ~0ull && (i == N - 1 || keys[i + 1] == ~0ull)) n_vis[view] = (uint32_t)(i + 1);
+    if (i < P) {
+      const uint32_t id = k != ~0ull ? (uint32_t)k : 0u;
+      sorted_id[base + i] = id;
+      sorted_rect[base + i] = k != ~0ull ? rect[base + id] : make_uint2(0u, 0u);
+    }
+  }
+}
+
+// ---- large P: LSD radix sort, 8-bit digits, 4096 keys per workgroup ---------------------------
+constexpr int RADIX_ITEMS = 16;               // keys per thread
+constexpr int RADIX_TILE = U3D_BLOCK * RADIX_ITEMS;  // 4096
+
+__device__ __forceinline__ uint32_t radix_key(int pass, int P, int idx, size_t base, const float* depth,
+                                              const int32_t* radii, const uint32_t* keys_in) {
+  if (pass == 0) return radii[base + idx] > 0 ? __float_as_uint(depth[base + idx]) : 0xFFFFFFFFu;
+  return keys_in[base + idx];
+}
+
+__global__ __launch_bounds__(U3D_BLOCK) void radix_hist_kernel(int pass, int P, int nblk, const float* __restrict__ depth,
+                                                               const int32_t* __restrict__ radii,
+                                                               const uint32_t* __restrict__ keys_in,
+                                                               uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[256];
+  const int view = blockIdx.y, blk = blockIdx.x;
+  const size_t base = (size_t)view * P;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll 4
+  for (int r = 0; r < RADIX_ITEMS; ++r) {
+    const int idx = blk * RADIX_TILE + r * U3D_BLOCK + threadIdx.x;
+    if (idx < P) {
+      const uint32_t k = radix_key(pass, P, idx, base, depth, radii, keys_in);
+      atomicAdd(&h[(k >> (8 * pass)) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  hist[((size_t)view * 256 + threadIdx.x) * nblk + blk] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(U3D_BLOCK) void radix_scan_kernel(int nblk, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t tot[256];
+  const int view = blockIdx.x, d = threadIdx.x;
+  uint32_t* row = hist + ((size_t)view * 256 + d) * nblk;
+  uint32_t s = 0;
+  for (int b = 0; b < nblk; ++b) s += row[b];
+  tot[d] = s;
+  __syncthreads();
+  // exclusive scan over 256 digit totals (Hillis-Steele in LDS)
+  for (int o = 1; o < 256; o <<= 1) {
+    const uint32_t v = d >= o ? tot[d - o] : 0u;
+    __syncthreads();
+    tot[d] += v;
+    __syncthreads();
+  }
+  uint32_t off = tot[d] - s;
+  for (int b = 0; b < nblk; ++b) {
+    const uint32_t c = row[b];
+    row[b] = off;
+    off += c;
+  }
+}
+
+__global__ __launch_bounds__(U3D_BLOCK) void radix_scatter_kernel(int pass, int P, int nblk, const float* __restrict__ depth,
+                                                                  const int32_t* __restrict__ radii,
+                                                                  const uint32_t* __restrict__ keys_in,
+                                                                  const uint32_t* __restrict__ vals_in,
+                                                                  uint32_t* __restrict__ keys_out,
+                                                                  uint32_t* __restrict__ vals_out,
+                                                                  const uint32_t* __restrict__ hist) {
+  __shared__ uint32_t digit_base[256];
+  __shared__ uint32_t wave_cnt[4][256];
+  const int view = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const uint32_t lane = u3d_lane_id();
+  const size_t base = (size_t)view * P;
+  digit_base[tid] = hist[((size_t)view * 256 + tid) * nblk + blk];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) wave_cnt[w][tid] = 0;
+  __syncthreads();
+  for (int r = 0; r < RADIX_ITEMS; ++r) {
+    const int idx = blk * RADIX_TILE + r * U3D_BLOCK + tid;
+    const bool valid = idx < P;
+    uint32_t k = 0, v = 0, digit = 0;
+    if (valid) {
+      k = radix_key(pass, P, idx, base, depth, radii, keys_in);
+      v = pass == 0 ? (uint32_t)idx : vals_in[base + idx];
+      digit = (k >> (8 * pass)) & 255u;
+    }
+    // lanes of this wave holding the same digit (stable multi-split via 8 ballots)
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (digit >> b) & 1u;
+      const unsigned long long m = __ballot(bit && valid);
+      same &= bit ? m : ~m;
+    }
+    const uint32_t rank = __popcll(same & ((1ull << lane) - 1ull));
+    if (valid && rank == 0) wave_cnt[wave][digit] = (uint32_t)__popcll(same);
+    __syncthreads();
+    if (valid) {
+      uint32_t dst = digit_base[digit] + rank;
+      for (int w = 0; w < wave; ++w) dst += wave_cnt[w][digit];
+      keys_out[base + dst] = k;
+      vals_out[base + dst] = v;
+    }
+    __syncthreads();
+    {
+      uint32_t add = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { add += wave_cnt[w][tid]; wave_cnt[w][tid] = 0; }
+      digit_base[tid] += add;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(U3D_BLOCK) void radix_finalize_kernel(int P, const uint32_t* __restrict__ keys,
+                                                                   const uint32_t* __restrict__ vals,
+                                                                   const uint2* __restrict__ rect,
+                                                                   uint32_t* __restrict__ sorted_id,
+                                                                   uint2* __restrict__ sorted_rect,
+                                                                   uint32_t* __restrict__ n_vis) {
+  const int view = blockIdx.y;
+  const int i = blockIdx.x * U3D_BLOCK + threadIdx.x;
+  if (i >= P) return;
+  const size_t base = (size_t)view * P;
+  const uint32_t k = keys[base + i];
+  const bool vis = k != 0xFFFFFFFFu;
+  const uint32_t id = vis ? vals[base + i] : 0u;
+  sorted_id[base + i] = id;
+  sorted_rect[base + i] = vis ? rect[base + id] : make_uint2(0u, 0u);
+  if (i == 0 && !vis) n_vis[view] = 0;
+  if (vis && (i == P - 1 || keys[base + i + 1] == 0xFFFFFFFFu)) n_vis[view] = (uint32_t)(i + 1);
+}
+
+}  // namespace
+
+void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const int32_t* radii, hipStream_t s) {
+  const int NV = d.n_items * d.views_per_item;
+  if (d.P <= U3D_LDS_SORT_MAX) {
+    int N = 64;
+    while (N < d.P) N <<= 1;
+    const int threads = N <= 512 ? 256 : 1024;
+    hipLaunchKernelGGL(depth_sort_lds_kernel, dim3(NV), dim3(threads), (size_t)N * sizeof(unsigned long long), s, d.P, N,
+                       b.depth, radii, b.rect, b.sorted_id, b.sorted_rect, b.n_vis);
+    return;
+  }
+  const int nblk = (d.P + RADIX_TILE - 1) / RADIX_TILE;
+  for (int pass = 0; pass < 4; ++pass) {
+    const uint32_t* kin = pass == 0 ? nullptr : b.sort_keys[(pass + 1) & 1];
+    const uint32_t* vin = pass == 0 ? nullptr : b.sort_vals[(pass + 1) & 1];
+    uint32_t* kout = b.sort_keys[pass & 1];
+    uint32_t* vout = b.sort_vals[pass & 1];
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin,
+                       b.sort_hist);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(NV), dim3(U3D_BLOCK), 0, s, nblk, b.sort_hist);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin,
+                       vin, kout, vout, b.sort_hist);
+  }
+  // pass 3 wrote buffer index 1
+  hipLaunchKernelGGL(radix_finalize_kernel, dim3((d.P + U3D_BLOCK - 1) / U3D_BLOCK, NV), dim3(U3D_BLOCK), 0, s, d.P,
+                     b.sort_keys[1], b.sort_vals[1], b.rect, b.sorted_id, b.sorted_rect, b.n_vis);
+}

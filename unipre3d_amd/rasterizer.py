@@ -1,0 +1,207 @@
+"""Python surface of the operator: `GaussianRasterizationSettings` + `GaussianRasterizer`.
+
+Mirrors what gaussian_renderer/__init__.py:8,45-61,89-97 needs from `diff_gaussian_rasterization`
+(SURVEY.md section 8b): a 13-field NamedTuple constructible by keyword, and an nn.Module called by
+keyword that returns the 3-tuple (color (3,H,W), radii (P,) int32, invdepth (1,H,W)) and is
+differentiable w.r.t. means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+cov3D_precomp.  The arithmetic runs in libunipre3d_rasterizer.so (hand-written gfx950 kernels) on
+torch's CURRENT stream, with no device->host synchronisation.
+
+`rasterize_gaussians_batched` is the same operator for B sets x V cameras in one launch sequence
+(replaces the Python loop of train_network.py:418-446).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    antialiasing: bool = False
+
+
+def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _none_if_empty(t):
+    return None if (t is None or t.numel() == 0) else t
+
+
+class _Plan:
+    """Descriptor + scratch sizes for one call shape."""
+
+    def __init__(self, n_items, vpi, P, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, M, flags):
+        self.desc = _lib.RasterDesc(n_items, vpi, P, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, M, flags)
+        self.sizes = _lib.ScratchSizes()
+        _lib.check(_lib.load().u3d_scratch_query(ctypes.byref(self.desc), ctypes.byref(self.sizes)), "u3d_scratch_query")
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _RasterizeFn(torch.autograd.Function):
+    """forward/backward pair over the C-ABI.  Tensor layout: leading dim = sets (items) for Gaussian
+    parameters, leading dim = views for cameras and outputs."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
+                projmatrix, campos, bg, n_items, vpi, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, flags):
+        lib = _lib.load()
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise RuntimeError("the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback "
+                               "(the CPU restatement lives in oracle/ and is test infrastructure only)")
+        P = means3D.shape[-2] if means3D.numel() > 0 else 0
+        M = shs.shape[-2] if shs is not None else 0
+        plan = _Plan(n_items, vpi, P, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, M, flags)
+        NV = n_items * vpi
+        color = torch.empty((NV, 3, H, W), dtype=torch.float32, device=dev)
+        invdepth = torch.empty((NV, 1, H, W), dtype=torch.float32, device=dev)
+        radii = torch.zeros((NV, P), dtype=torch.int32, device=dev)
+        geom = torch.empty(plan.sizes.geom_bytes, dtype=torch.uint8, device=dev)
+        binning = torch.empty(plan.sizes.binning_bytes, dtype=torch.uint8, device=dev)
+        image = torch.empty(plan.sizes.image_bytes, dtype=torch.uint8, device=dev)
+        p = _lib.ptr
+        rc = lib.u3d_rasterize_forward(ctypes.byref(plan.desc), p(bg), p(means3D), p(shs), p(colors_precomp), p(opacities),
+                                       p(scales), p(rotations), p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos),
+                                       p(color), p(invdepth), p(radii), p(geom), p(binning), p(image), _stream_ptr())
+        _lib.check(rc, "u3d_rasterize_forward")
+        ctx.plan = plan
+        ctx.has = (shs is not None, colors_precomp is not None, scales is not None, cov3D_precomp is not None)
+        ctx.save_for_backward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
+                              projmatrix, campos, bg, radii, geom, binning, image)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, invdepth
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii, grad_invdepth):
+        lib = _lib.load()
+        (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, bg,
+         radii, geom, binning, image) = ctx.saved_tensors
+        plan = ctx.plan
+        d = plan.desc
+        dev = means3D.device
+        NV, P, M = d.n_items * d.views_per_item, d.P, d.sh_coeffs
+        grad_color = _f32c(grad_color, dev)
+        grad_invdepth = _f32c(grad_invdepth, dev) if grad_invdepth is not None else None
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        g_means3D, g_means2D, g_op = z(d.n_items, P, 3), z(NV, P, 3), z(d.n_items, P, 1)
+        g_shs = z(d.n_items, P, M, 3) if shs is not None else None
+        g_col = z(d.n_items, P, 3)
+        g_scales = z(d.n_items, P, 3) if scales is not None else None
+        g_rot = z(d.n_items, P, 4) if scales is not None else None
+        g_cov = z(d.n_items, P, 6) if cov3D_precomp is not None else None
+        if P > 0 and NV > 0:
+            scratch = torch.empty(plan.sizes.backward_bytes, dtype=torch.uint8, device=dev)
+            p = _lib.ptr
+            rc = lib.u3d_rasterize_backward(
+                ctypes.byref(d), p(bg), p(means3D), p(shs), p(colors_precomp), p(opacities), p(scales), p(rotations),
+                p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos), p(radii), p(grad_color), p(grad_invdepth),
+                p(geom), p(binning), p(image), p(scratch), p(g_means3D), p(g_means2D), p(g_shs), p(g_col), p(g_op),
+                p(g_scales), p(g_rot), p(g_cov), _stream_ptr())
+            _lib.check(rc, "u3d_rasterize_backward")
+        return (g_means3D, g_means2D, g_shs, g_col if colors_precomp is not None else None, g_op, g_scales, g_rot, g_cov,
+                None, None, None, None, None, None, None, None, None, None, None, None, None)
+
+
+def _flags(settings: GaussianRasterizationSettings, exact_aa_grad: bool = False) -> int:
+    return ((_lib.FLAG_PREFILTERED if settings.prefiltered else 0) | (_lib.FLAG_ANTIALIASING if settings.antialiasing else 0)
+            | (_lib.FLAG_DEBUG if settings.debug else 0) | (_lib.FLAG_EXACT_AA_GRAD if exact_aa_grad else 0))
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings: GaussianRasterizationSettings, exact_aa_grad: bool = False):
+    """One view (the reference's operator).  Shapes: means3D (P,3), means2D (P,3), sh (P,M,3) | colors (P,3),
+    opacities (P,1), scales (P,3), rotations (P,4) | cov3D (P,6)."""
+    s = raster_settings
+    dev = means3D.device
+    sh, colors_precomp = _none_if_empty(sh), _none_if_empty(colors_precomp)
+    scales, rotations, cov3Ds_precomp = _none_if_empty(scales), _none_if_empty(rotations), _none_if_empty(cov3Ds_precomp)
+    P = means3D.shape[0]
+    un = lambda t: None if t is None else _f32c(t, dev).unsqueeze(0)
+    color, radii, invdepth = _RasterizeFn.apply(
+        un(means3D), un(means2D if means2D is not None else torch.zeros_like(means3D)), un(sh), un(colors_precomp),
+        un(opacities.reshape(P, 1)), un(scales), un(rotations), un(cov3Ds_precomp), _f32c(s.viewmatrix, dev).reshape(1, 16),
+        _f32c(s.projmatrix, dev).reshape(1, 16), _f32c(s.campos, dev).reshape(1, 3), _f32c(s.bg, dev).reshape(3), 1, 1,
+        int(s.image_height), int(s.image_width), float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier),
+        int(s.sh_degree), _flags(s, exact_aa_grad))
+    return color[0], radii[0], invdepth[0]
+
+
+def rasterize_gaussians_batched(means3D, opacities, viewmatrix, projmatrix, campos, bg, image_height, image_width, tanfovx,
+                                tanfovy, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+                                sh_degree=0, scale_modifier=1.0, antialiasing=True, debug=False, exact_aa_grad=False):
+    """B sets x V cameras in ONE launch sequence.
+    means3D (B,P,3), opacities (B,P,1), shs (B,P,M,3) | colors_precomp (B,P,3), scales (B,P,3) + rotations (B,P,4) |
+    cov3D_precomp (B,P,6); viewmatrix/projmatrix (B,V,4,4), campos (B,V,3), bg (3,).
+    Returns color (B,V,3,H,W), radii (B,V,P) int32, invdepth (B,V,1,H,W)."""
+    if (shs is None) == (colors_precomp is None):
+        raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+            ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+    dev = means3D.device
+    B, P = means3D.shape[0], means3D.shape[1]
+    V = viewmatrix.shape[1]
+    flags = (_lib.FLAG_ANTIALIASING if antialiasing else 0) | (_lib.FLAG_DEBUG if debug else 0) | \
+        (_lib.FLAG_EXACT_AA_GRAD if exact_aa_grad else 0)
+    f = lambda t: _f32c(t, dev)
+    color, radii, invdepth = _RasterizeFn.apply(
+        f(means3D), torch.zeros(B * V, P, 3, device=dev), f(shs), f(colors_precomp), f(opacities).reshape(B, P, 1), f(scales),
+        f(rotations), f(cov3D_precomp), f(viewmatrix).reshape(B * V, 16), f(projmatrix).reshape(B * V, 16),
+        f(campos).reshape(B * V, 3), f(bg).reshape(3), B, V, int(image_height), int(image_width), float(tanfovx),
+        float(tanfovy), float(scale_modifier), int(sh_degree), flags)
+    return (color.reshape(B, V, 3, image_height, image_width), radii.reshape(B, V, P),
+            invdepth.reshape(B, V, 1, image_height, image_width))
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        s = self.raster_settings
+        with torch.no_grad():
+            pos = _f32c(positions, positions.device)
+            P = pos.shape[0]
+            present = torch.zeros(P, dtype=torch.uint8, device=pos.device)
+            rc = _lib.load().u3d_mark_visible(P, _lib.ptr(pos), _lib.ptr(_f32c(s.viewmatrix, pos.device)),
+                                              _lib.ptr(_f32c(s.projmatrix, pos.device)), _lib.ptr(present), _stream_ptr())
+            _lib.check(rc, "u3d_mark_visible")
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)
