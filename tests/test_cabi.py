@@ -1,0 +1,101 @@
+"""C-ABI library: loads without a GPU, exports every symbol include/unipre3d_rasterizer.h declares, host-only
+entry points (scratch query, argument checks) behave.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from unipre3d_amd import _lib
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def _declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "unipre3d_rasterizer.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(u3d_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared_functions()
+    assert set(names) == set(_lib.EXPORTS)
+    for n in names:
+        assert getattr(lib, n) is not None
+    assert lib.u3d_abi_version() == 1
+    assert lib.u3d_error_string(0) == b"ok" and b"invalid" in lib.u3d_error_string(1)
+
+
+def test_header_and_ctypes_struct_agree():
+    hdr = open(os.path.join(ROOT, "include", "unipre3d_rasterizer.h")).read()
+    body = re.search(r"typedef struct u3d_raster_desc \{(.*?)\} u3d_raster_desc;", hdr, re.S).group(1)
+    fields = re.findall(r"^\s*(?:int32_t|float)\s+(\w+);", body, re.M)
+    assert fields == [f[0] for f in _lib.RasterDesc._fields_]
+    body = re.search(r"typedef struct u3d_scratch_sizes \{(.*?)\} u3d_scratch_sizes;", hdr, re.S).group(1)
+    fields = re.findall(r"^\s*size_t\s+(\w+);", body, re.M)
+    assert fields == [f[0] for f in _lib.ScratchSizes._fields_]
+
+
+def test_scratch_query_is_host_arithmetic(lib):
+    d = _lib.RasterDesc(32, 4, 128, 256, 256, 0.457, 0.457, 1.0, 1, 4, _lib.FLAG_ANTIALIASING)
+    s = _lib.ScratchSizes()
+    assert lib.u3d_scratch_query(ctypes.byref(d), ctypes.byref(s)) == 0
+    NG, NP = 32 * 4 * 128, 32 * 4 * 256 * 256
+    assert s.geom_bytes >= NG * (4 + 8 + 16 + 16 + 8 + 4)
+    assert s.image_bytes >= NP * 8 and s.backward_bytes >= NG * 40 and s.binning_bytes >= NG * 12
+    assert s.num_rendered_offset % 256 == 0 and s.num_rendered_offset < s.geom_bytes
+    # radix temporaries only beyond the LDS-sortable size
+    d2 = _lib.RasterDesc(1, 8, 200000, 480, 640, 0.55, 0.55, 1.0, 1, 4, 2)
+    s2 = _lib.ScratchSizes()
+    assert lib.u3d_scratch_query(ctypes.byref(d2), ctypes.byref(s2)) == 0
+    assert s2.binning_bytes >= 8 * 200000 * (12 + 16)
+    # empty call is legal
+    d0 = _lib.RasterDesc(1, 1, 0, 16, 16, 0.5, 0.5, 1.0, 0, 0, 0)
+    assert lib.u3d_scratch_query(ctypes.byref(d0), ctypes.byref(s)) == 0
+
+
+def test_argument_errors_without_touching_the_device(lib):
+    s = _lib.ScratchSizes()
+    bad = _lib.RasterDesc(1, 1, 8, 0, 16, 0.5, 0.5, 1.0, 1, 4, 0)
+    assert lib.u3d_scratch_query(ctypes.byref(bad), ctypes.byref(s)) == 1
+    bad = _lib.RasterDesc(1, 1, 8, 16, 16, 0.5, 0.5, 1.0, 4, 25, 0)   # SH degree 4 not supported
+    assert lib.u3d_scratch_query(ctypes.byref(bad), ctypes.byref(s)) == 2
+    ok = _lib.RasterDesc(1, 1, 8, 16, 16, 0.5, 0.5, 1.0, 1, 4, 0)
+    null = ctypes.c_void_p(0)
+    # NULL mandatory pointers are rejected before any launch
+    assert lib.u3d_rasterize_forward(ctypes.byref(ok), *([null] * 18)) == 1
+    assert lib.u3d_rasterize_backward(ctypes.byref(ok), *([null] * 27)) == 1
+    assert lib.u3d_mark_visible(4, null, null, null, null, null) == 1
+    assert lib.u3d_mark_visible(0, null, null, null, null, null) == 0
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from unipre3d_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    st = GaussianRasterizationSettings(16, 16, 0.5, 0.5, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 0, torch.zeros(3),
+                                       False, False, True)
+    r = GaussianRasterizer(st)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        r(means3D=torch.zeros(4, 3), means2D=torch.zeros(4, 3), opacities=torch.ones(4, 1), colors_precomp=torch.ones(4, 3),
+          scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(means3D=torch.zeros(4, 3), means2D=torch.zeros(4, 3), opacities=torch.ones(4, 1), scales=torch.ones(4, 3),
+          rotations=torch.ones(4, 4))
+    with pytest.raises(Exception, match="scale/rotation pair"):
+        r(means3D=torch.zeros(4, 3), means2D=torch.zeros(4, 3), opacities=torch.ones(4, 1), colors_precomp=torch.ones(4, 3))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "unipre3d_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+    src = open(os.path.join(ROOT, "diff_gaussian_rasterization", "__init__.py")).read()
+    assert "oracle" not in src

@@ -1,0 +1,124 @@
+"""Batched operator, drop-in module name, render-loss step and full-size properties (BASELINE config C2)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _batch(B, P, V, H, W, level="object", seed=42, compact=False):
+    from unipre3d_amd import synthetic
+    b = synthetic.make_batch(B, P, V, H, W, level=level, seed=seed, compact=compact)
+    return b, b.to(torch.device("cuda:0"))
+
+
+def test_batched_equals_per_view_operator_and_oracle(oracle_mod):
+    """C1 geometry: B=2 objects x V=4 views, 128 Gaussians, 128x128."""
+    from unipre3d_amd import head, renderer, synthetic
+    import diff_gaussian_rasterization as dgr           # the reference's import name resolves to our module
+    b, bd = _batch(2, 128, 4, 128, 128)
+    bd.raw.requires_grad_(True)
+    g = synthetic.gaussians_from_batch(bd)
+    out = renderer.render_views(g, bd.world_view, bd.full_proj, bd.camera_center, bd.bg, bd.fov_deg, 128, 128)
+    assert out.shape == (8, 3, 128, 128)
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).cuda()
+    (out * w).sum().backward()
+    g_batched = bd.raw.grad.clone()
+    # the per-view route, exactly as the reference loops (train_network.py:418-446)
+    bd.raw.grad = None
+    g2 = synthetic.gaussians_from_batch(bd)
+    t = math.tan(bd.fov_deg * math.pi / 360)
+    imgs = []
+    for bi in range(2):
+        for v in range(4):
+            st = dgr.GaussianRasterizationSettings(128, 128, t, t, bd.bg, 1.0, bd.world_view[bi, v], bd.full_proj[bi, v], 1,
+                                                   bd.camera_center[bi, v], False, False, True)
+            shs = head.concat_sh(g2["features_dc"][bi], g2["features_rest"][bi])
+            img, radii, _ = dgr.GaussianRasterizer(st)(means3D=g2["xyz"][bi], means2D=torch.zeros_like(g2["xyz"][bi]),
+                                                       opacities=g2["opacity"][bi], shs=shs, scales=g2["scaling"][bi],
+                                                       rotations=g2["rotation"][bi])
+            imgs.append(img)
+    per_view = torch.stack(imgs)
+    (per_view * w).sum().backward()
+    assert rel_l2(out.detach().cpu().numpy(), per_view.detach().cpu().numpy()) < 1e-6
+    assert rel_l2(g_batched.cpu().numpy(), bd.raw.grad.cpu().numpy()) < 1e-4
+    # and against the oracle, view by view
+    gc = {k: v.detach().cpu() for k, v in g2.items()}
+    for bi in range(2):
+        shs = head.concat_sh(gc["features_dc"][bi], gc["features_rest"][bi]).numpy()
+        for v in range(4):
+            r = oracle_mod.forward(gc["xyz"][bi].numpy(), gc["opacity"][bi].numpy(), b.world_view[bi, v].numpy(),
+                                   b.full_proj[bi, v].numpy(), b.camera_center[bi, v].numpy(), b.bg.numpy(), 128, 128, t, t,
+                                   shs=shs, scales=gc["scaling"][bi].numpy(), rotations=gc["rotation"][bi].numpy(), sh_degree=1)
+            assert rel_l2(out[bi * 4 + v].detach().cpu().numpy(), r.color) < TOL
+
+
+def test_reference_style_render_predicted_runs_on_device():
+    from unipre3d_amd import renderer, synthetic
+
+    class NS:
+        def __init__(self, **k):
+            self.__dict__.update(k)
+    b, bd = _batch(1, 128, 2, 128, 128)
+    g = synthetic.gaussians_from_batch(bd)
+    pc = {k: v[0] for k, v in g.items()}
+    cfg = NS(data=NS(fov=bd.fov_deg, training_resolution=128), model=NS(max_sh_degree=1))
+    out = renderer.render_predicted(pc, bd.world_view[0, 0], bd.full_proj[0, 0], bd.camera_center[0, 0], bd.bg, cfg)
+    assert out["render"].shape == (3, 128, 128) and out["radii"].shape == (128,) and out["radii"].dtype == torch.int32
+    assert out["visibility_filter"].dtype == torch.bool and torch.isfinite(out["render"]).all()
+    batched = renderer.render_views(g, bd.world_view, bd.full_proj, bd.camera_center, bd.bg, bd.fov_deg, 128, 128)
+    assert rel_l2(out["render"].detach().cpu().numpy(), batched[0].detach().cpu().numpy()) < 1e-6
+
+
+def test_scene_level_batched_vs_oracle(oracle_mod):
+    """Scene-level geometry (white background, 4:3 image with one fov, P above the LDS-sort limit)."""
+    from unipre3d_amd import head, renderer, synthetic
+    b, bd = _batch(1, 6000, 3, 120, 160, level="scene", seed=7)
+    g = synthetic.gaussians_from_batch(bd)
+    out = renderer.render_views(g, bd.world_view, bd.full_proj, bd.camera_center, bd.bg, bd.fov_deg, 120, 160)
+    t = math.tan(bd.fov_deg * math.pi / 360)
+    gc = {k: v.detach().cpu() for k, v in g.items()}
+    shs = head.concat_sh(gc["features_dc"][0], gc["features_rest"][0]).numpy()
+    for v in range(3):
+        r = oracle_mod.forward(gc["xyz"][0].numpy(), gc["opacity"][0].numpy(), b.world_view[0, v].numpy(),
+                               b.full_proj[0, v].numpy(), b.camera_center[0, v].numpy(), b.bg.numpy(), 120, 160, t, t, shs=shs,
+                               scales=gc["scaling"][0].numpy(), rotations=gc["rotation"][0].numpy(), sh_degree=1)
+        assert rel_l2(out[v].detach().cpu().numpy(), r.color) < TOL
+
+
+def test_full_size_C2_properties(oracle_mod):
+    """BASELINE config C2 (B=32, V=4, P=128, 256x256): size-independent properties + spot checks vs the oracle."""
+    from unipre3d_amd import head, losses, renderer, synthetic
+    b, bd = _batch(32, 128, 4, 256, 256)
+    bd.raw.requires_grad_(True)
+    g = synthetic.gaussians_from_batch(bd)
+    out = renderer.render_views(g, bd.world_view, bd.full_proj, bd.camera_center, bd.bg, bd.fov_deg, 256, 256)
+    assert out.shape == (128, 3, 256, 256) and torch.isfinite(out).all()
+    # black background + colours clamped >= 0 -> image >= 0 ; transmittance bound: each channel <= max colour
+    assert out.min().item() >= 0.0
+    loss = losses.render_loss(out, bd.gt.reshape(128, 3, 256, 256), "focal_l2")
+    loss.backward()
+    assert torch.isfinite(bd.raw.grad).all() and bd.raw.grad.abs().sum().item() > 0
+    # determinism of the forward (no atomics there): two runs are bit-identical
+    out2 = renderer.render_views(synthetic.gaussians_from_batch(bd), bd.world_view, bd.full_proj, bd.camera_center, bd.bg,
+                                 bd.fov_deg, 256, 256)
+    assert torch.equal(out, out2)
+    # linearity of the backward in the cotangent: grad(2w) == 2 grad(w)
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).cuda()
+    g1, = torch.autograd.grad((out2 * w).sum(), bd.raw, retain_graph=True)
+    g2, = torch.autograd.grad((out2 * (2 * w)).sum(), bd.raw)
+    assert rel_l2(g2.cpu().numpy(), 2 * g1.cpu().numpy()) < 1e-5
+    # spot-check 3 of the 128 views against the oracle at full resolution
+    t = math.tan(bd.fov_deg * math.pi / 360)
+    gc = {k: v.detach().cpu() for k, v in g.items()}
+    for (bi, v) in ((0, 0), (13, 2), (31, 3)):
+        shs = head.concat_sh(gc["features_dc"][bi], gc["features_rest"][bi]).numpy()
+        r = oracle_mod.forward(gc["xyz"][bi].numpy(), gc["opacity"][bi].numpy(), b.world_view[bi, v].numpy(),
+                               b.full_proj[bi, v].numpy(), b.camera_center[bi, v].numpy(), b.bg.numpy(), 256, 256, t, t,
+                               shs=shs, scales=gc["scaling"][bi].numpy(), rotations=gc["rotation"][bi].numpy(), sh_degree=1)
+        assert rel_l2(out[bi * 4 + v].detach().cpu().numpy(), r.color) < TOL
