@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the render-loss hot path on MI355X (contract: see DESIGN.md section "Measurement").
+
+A step = one pass of the hot path over one synthetic batch resident in HBM:
+  Gaussian head (PyTorch, the reference's `final` MLP) -> head activations (R1) -> batched HIP rasterizer forward
+  (R4/R7) -> focal-L2 render loss (R8) -> HIP rasterizer backward (R5) -> head backward -> [DDP gradient
+  all-reduce over RCCL when N > 1 (R9)] -> grad clip -> AdamW step.
+Workload at N=1: BASELINE.json configs[1] (C2): transformer config, 128 Gaussians per object (1024 pts -> 128
+groups), 256x256, batch 32 per GPU x 4 supervised views = 128 rendered views per step.  Weak scaling: every
+rank renders its own 32 objects.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from unipre3d_amd import _lib, dp, step, synthetic  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(kind: str, P: int, R: float, T: int, HW: int) -> float:
+    """Per-view algorithmic bytes of each kernel (DESIGN.md 'Algorithmic bytes').
+    forward total 168 P + 76 R + 8 T + 24 HW, backward total 308 P + 76 R + 24 HW."""
+    return {
+        "preprocess_fwd": 168.0 * P,
+        "depth_sort": 36.0 * R,               # key/value write 12 + sort read 12 + sort write 12 of the reference algorithm
+        "render_fwd": 40.0 * R + 8.0 * T + 24.0 * HW,
+        "render_bwd": 76.0 * R + 24.0 * HW,
+        "preprocess_bwd": 308.0 * P,
+    }[kind]
+
+
+def cpu_baseline(batch, H, W, min_seconds=10.0, max_views=8):
+    """The CPU restatement (oracle/, kind 'port') timed on a bounded sample of the SAME workload:
+    forward + focal-L2 + backward for the first `max_views` views, repeated until >= min_seconds."""
+    import numpy as np
+    from oracle import oracle
+    from unipre3d_amd import head, losses
+    oracle.build()
+    g = synthetic.gaussians_from_batch(batch)
+    t = math.tan(batch.fov_deg * math.pi / 360)
+    V = batch.world_view.shape[1]
+    views = [(b, v) for b in range(batch.raw.shape[0]) for v in range(V)][:max_views]
+    args = []
+    for (b, v) in views:
+        shs = head.concat_sh(g["features_dc"][b], g["features_rest"][b]).numpy()
+        args.append(dict(means3D=g["xyz"][b].numpy(), opacities=g["opacity"][b].numpy(), viewmatrix=batch.world_view[b, v].numpy(),
+                         projmatrix=batch.full_proj[b, v].numpy(), campos=batch.camera_center[b, v].numpy(), bg=batch.bg.numpy(),
+                         image_height=H, image_width=W, tanfovx=t, tanfovy=t, shs=shs, scales=g["scaling"][b].numpy(),
+                         rotations=g["rotation"][b].numpy(), sh_degree=1, dtype=np.float32))
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for a, (b, v) in zip(args, views):
+            r = oracle.forward(**a)
+            x = torch.from_numpy(r.color)[None].requires_grad_(True)
+            loss = losses.render_loss(x, batch.gt[b, v][None], "focal_l2")
+            (gx,) = torch.autograd.grad(loss, x)
+            oracle.backward(r, gx[0].numpy())
+            r.close()
+            n += 1
+        el = time.perf_counter() - t0
+        if el >= min_seconds:
+            break
+    return {"value": n / el, "unit": "views/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"{len(views)} views of the bench batch (fwd + focal_l2 + bwd), repeated for {el:.1f} s = {n} renders"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="C2", choices=sorted(synthetic.CONFIGS))
+    ap.add_argument("--compact", action="store_true", help="secondary compact-splat regime (SURVEY 8d)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    a = ap.parse_args()
+
+    rank, local_rank, world = dp.init_from_env()
+    if world != a.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {a.gpus}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = synthetic.CONFIGS[a.config]
+    B, P, V, H, W, level = cfg["B"], cfg["P"], cfg["V"], cfg["H"], cfg["W"], cfg["level"]
+    host_batch = synthetic.make_batch(B, P, V, H, W, level=level, seed=42 + rank, compact=a.compact)
+    batch = host_batch.to(dev)
+    feat_dim = 384 if level == "object" else 64
+    torch.manual_seed(42)  # identical initial weights on every rank
+    model = dp.GaussianHead(feat_dim, 128 if level == "object" else 32).to(dev)
+    # synthetic backbone features whose head output has the N(0,1) statistics of SURVEY 8d
+    feats = torch.randn(B, P, feat_dim, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+    with torch.no_grad():
+        raw0 = model(feats)
+        model.final[2].weight.div_(raw0.std())
+        model.final[2].bias.zero_()
+    model = dp.create_ddp_model(model, sync_bn=False)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, eps=1e-15)  # train_network.py:156-158 (group lr 1e-4)
+    loss_kind = "focal_l2" if level == "object" else "l2"
+
+    def one_step():
+        return step.train_step(model, feats, batch, opt, H, W, 0, loss_kind)
+
+    for _ in range(a.warmup):
+        one_step()
+    dp.synchronize()
+    torch.cuda.synchronize()
+    _lib.profile_begin(8 * (a.steps + 2) * 8)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    dp.synchronize()
+    t1 = time.perf_counter()
+    prof = _lib.profile_end()
+    elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = elapsed.item()
+
+    # statistics of the workload (outside the timed region): R = num_rendered
+    from unipre3d_amd.rasterizer import _RasterizeFn  # noqa: F401
+    with torch.no_grad():
+        g = synthetic.gaussians_from_batch(batch)
+        from unipre3d_amd import head
+        from unipre3d_amd.rasterizer import rasterize_gaussians_batched
+        t = math.tan(batch.fov_deg * math.pi / 360)
+        color, radii, _ = rasterize_gaussians_batched(g["xyz"], g["opacity"], batch.world_view, batch.full_proj, batch.camera_center,
+                                                      batch.bg, H, W, t, t, shs=head.concat_sh(g["features_dc"], g["features_rest"]),
+                                                      scales=g["scaling"], rotations=g["rotation"], sh_degree=1)
+    if rank == 0:
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        # R from the Gaussian rects: visible Gaussians x tiles touched is accumulated by the kernel; read it back via radii>0
+        # (exact value is in the geom scratch; recompute from an extra forward on a fresh plan for reporting)
+        from unipre3d_amd.rasterizer import _Plan
+        R_mean = _read_num_rendered(g, batch, H, W, t)
+        NV = B * V
+        kernels = {}
+        for k, (ms, cnt) in prof.items():
+            if cnt:
+                avg_ms = ms / cnt
+                by = algorithmic_bytes(k, P, R_mean, tiles, H * W) * NV
+                kernels[k] = {"avg_ms": avg_ms, "launches": cnt, "algorithmic_GB_per_launch": by / 1e9,
+                              "achieved_GBs": by / 1e9 / (avg_ms / 1e3)}
+        hot = {k: v for k, v in kernels.items() if k in ("render_fwd", "render_bwd")}
+        dom = max(hot, key=lambda k: hot[k]["avg_ms"]) if hot else None
+        fwd_ms = sum(kernels[k]["avg_ms"] for k in ("preprocess_fwd", "depth_sort", "render_fwd") if k in kernels)
+        bwd_ms = sum(kernels[k]["avg_ms"] for k in ("render_bwd", "preprocess_bwd") if k in kernels)
+        fwd_bytes = (168.0 * P + 76.0 * R_mean + 8.0 * tiles + 24.0 * H * W) * NV
+        bwd_bytes = (308.0 * P + 76.0 * R_mean + 24.0 * H * W) * NV
+        out = {
+            "metric": "rendered_views_per_sec", "value": world * NV * a.steps / elapsed, "unit": "views/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.config}: render-loss step, {level}-level, P={P} Gaussians/object, {H}x{W}, "
+                                   f"B={B}/GPU x V={V} views = {NV} renders/GPU/step" + (" (compact splats)" if a.compact else ""),
+                       "global_batch": B * world, "views_per_step": NV * world, "parallelism": f"dp{world}",
+                       "loss": loss_kind, "num_rendered_per_view": R_mean},
+            "render_loss_step_ms": {"rasterizer_fwd_kernels": fwd_ms, "rasterizer_bwd_kernels": bwd_ms, "kernels": kernels},
+            "final_loss": float(loss),
+        }
+        if dom:
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None}
+            out["roofline_forward_rasterizer"] = {"achieved": fwd_bytes / 1e9 / (fwd_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": fwd_bytes / 1e9 / (fwd_ms / 1e3) / HBM_PEAK_GBS,
+                                                  "note": "reference-algorithm bytes 168P+76R+8T+24HW per view over the sum of forward kernel times"}
+            out["roofline_backward_rasterizer"] = {"achieved": bwd_bytes / 1e9 / (bwd_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": bwd_bytes / 1e9 / (bwd_ms / 1e3) / HBM_PEAK_GBS}
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(host_batch, H, W, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _read_num_rendered(g, batch, H, W, t) -> float:
+    """Mean over views of R = sum over Gaussians of tiles touched, read from the kernel's own counter."""
+    import ctypes
+    from unipre3d_amd import head
+    from unipre3d_amd.rasterizer import _Plan
+    B, P = g["xyz"].shape[:2]
+    V = batch.world_view.shape[1]
+    dev = g["xyz"].device
+    plan = _Plan(B, V, P, H, W, t, t, 1.0, 1, 4, _lib.FLAG_ANTIALIASING)
+    NV = B * V
+    color = torch.empty((NV, 3, H, W), device=dev); radii = torch.zeros((NV, P), dtype=torch.int32, device=dev)
+    geom = torch.empty(plan.sizes.geom_bytes, dtype=torch.uint8, device=dev)
+    binning = torch.empty(plan.sizes.binning_bytes, dtype=torch.uint8, device=dev)
+    image = torch.empty(plan.sizes.image_bytes, dtype=torch.uint8, device=dev)
+    p = _lib.ptr
+    shs = head.concat_sh(g["features_dc"], g["features_rest"])
+    c = lambda x: x.contiguous()
+    rc = _lib.load().u3d_rasterize_forward(
+        ctypes.byref(plan.desc), p(batch.bg), p(c(g["xyz"])), p(c(shs)), p(None), p(c(g["opacity"])), p(c(g["scaling"])),
+        p(c(g["rotation"])), p(None), p(c(batch.world_view).reshape(NV, 16)), p(c(batch.full_proj).reshape(NV, 16)),
+        p(c(batch.camera_center).reshape(NV, 3)), p(color), p(None), p(radii), p(geom), p(binning), p(image),
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "u3d_rasterize_forward")
+    torch.cuda.synchronize()
+    off = plan.sizes.num_rendered_offset
+    nr = geom[off:off + 4 * NV].view(torch.int32).to(torch.float64)
+    return float(nr.mean().item())
+
+
+if __name__ == "__main__":
+    main()

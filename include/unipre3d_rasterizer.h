@@ -126,6 +126,19 @@ int u3d_rasterize_backward(const u3d_raster_desc* desc, const float* bg, const f
 int u3d_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);
 
+/*
+ * Measurement hooks (bench.py / profiling only; no reference counterpart).  While enabled, every kernel
+ * of the launch sequences is bracketed by a pair of HIP events recorded on the caller's stream, so that
+ * per-kernel durations can be read without an external profiler.
+ *   kind: 0 preprocess_fwd, 1 depth_sort, 2 render_fwd, 3 render_bwd, 4 preprocess_bwd
+ * u3d_profile_begin(max_records) allocates the event ring and enables recording (U3D_ERR_INVALID_ARGUMENT
+ * if already enabled); u3d_profile_end waits for the recorded events, writes total milliseconds and launch
+ * counts per kind into ms[U3D_PROFILE_KINDS] / count[U3D_PROFILE_KINDS], frees the events and disables.
+ */
+#define U3D_PROFILE_KINDS 5
+int u3d_profile_begin(int32_t max_records);
+int u3d_profile_end(float* ms, int32_t* count);
+
 #ifdef __cplusplus
 }
 #endif

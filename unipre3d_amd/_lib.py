@@ -20,7 +20,8 @@ CSRC = os.path.join(_HERE, "csrc")
 FLAG_PREFILTERED, FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_EXACT_AA_GRAD = 1, 2, 4, 8
 
 EXPORTS = ("u3d_abi_version", "u3d_error_string", "u3d_scratch_query", "u3d_rasterize_forward",
-           "u3d_rasterize_backward", "u3d_mark_visible")
+           "u3d_rasterize_backward", "u3d_mark_visible", "u3d_profile_begin", "u3d_profile_end")
+PROFILE_KINDS = ("preprocess_fwd", "depth_sort", "render_fwd", "render_bwd", "preprocess_bwd")
 
 
 class RasterDesc(ctypes.Structure):
@@ -70,6 +71,10 @@ def load() -> ctypes.CDLL:
     lib.u3d_rasterize_backward.argtypes = [ctypes.POINTER(RasterDesc)] + [vp] * 27
     lib.u3d_mark_visible.restype = ctypes.c_int
     lib.u3d_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.u3d_profile_begin.restype = ctypes.c_int
+    lib.u3d_profile_begin.argtypes = [i32]
+    lib.u3d_profile_end.restype = ctypes.c_int
+    lib.u3d_profile_end.argtypes = [vp, vp]
     if lib.u3d_abi_version() != 1:
         raise RuntimeError("libunipre3d_rasterizer.so ABI version mismatch; rebuild")
     _lib = lib
@@ -84,3 +89,15 @@ def check(code: int, what: str) -> None:
 def ptr(t) -> ctypes.c_void_p:
     """Device pointer of a tensor (None -> NULL)."""
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def profile_begin(max_records: int = 65536) -> None:
+    check(load().u3d_profile_begin(max_records), "u3d_profile_begin")
+
+
+def profile_end() -> dict:
+    """{kind: (total_ms, launches)} for the kernels enqueued since profile_begin()."""
+    ms = (ctypes.c_float * len(PROFILE_KINDS))()
+    cnt = (ctypes.c_int32 * len(PROFILE_KINDS))()
+    check(load().u3d_profile_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p)), "u3d_profile_end")
+    return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(PROFILE_KINDS)}

@@ -6,7 +6,30 @@
 
 void u3d_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
+#include <vector>
+
 namespace {
+
+// ---- optional per-kernel HIP-event timing (u3d_profile_begin / _end) ---------------------------
+struct ProfRec { hipEvent_t a, b; int kind; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;   // pre-created events
+size_t g_prof_used = 0;
+
+struct ProfScope {
+  ProfRec* r = nullptr;
+  hipStream_t s;
+  ProfScope(int kind, hipStream_t st) : s(st) {
+    if (g_prof_on && g_prof_used < g_prof.size()) {
+      r = &g_prof[g_prof_used++];
+      r->kind = kind;
+      (void)hipEventRecord(r->a, s);
+    }
+  }
+  ~ProfScope() {
+    if (r) (void)hipEventRecord(r->b, s);
+  }
+};
 
 int check_desc(const u3d_raster_desc* d) {
   if (!d) return U3D_ERR_INVALID_ARGUMENT;
@@ -88,11 +111,20 @@ int u3d_rasterize_forward(const u3d_raster_desc* desc, const float* bg, const fl
   (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
   (void)hipMemsetAsync(b.n_vis, 0, sizeof(uint32_t) * NV, s);
   if (d.P > 0) {
-    u3d_launch_preprocess_fwd(d, b, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
-                              projmatrix, campos, radii, s);
-    u3d_launch_depth_sort(d, b, radii, s);
+    {
+      ProfScope ps(0, s);
+      u3d_launch_preprocess_fwd(d, b, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                viewmatrix, projmatrix, campos, radii, s);
+    }
+    {
+      ProfScope ps(1, s);
+      u3d_launch_depth_sort(d, b, radii, s);
+    }
   }
-  u3d_launch_render_fwd(d, b, bg, out_color, out_invdepth, s);
+  {
+    ProfScope ps(2, s);
+    u3d_launch_render_fwd(d, b, bg, out_color, out_invdepth, s);
+  }
   return finish(desc, s);
 }
 
@@ -122,10 +154,16 @@ int u3d_rasterize_backward(const u3d_raster_desc* desc, const float* bg, const f
   const U3DLayout L = u3d_carve(d, (void*)geom, (void*)binning, (void*)image, &b);
   float* acc = (float*)backward_scratch;
   (void)hipMemsetAsync(acc, 0, L.backward_bytes, s);
-  u3d_launch_render_bwd(d, b, bg, dL_dcolor, dL_dinvdepth, acc, s);
-  u3d_launch_preprocess_bwd(d, b, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
-                            projmatrix, campos, radii, acc, dL_dmeans3D, dL_dmeans2D, shs ? dL_dshs : nullptr, dL_dcolors,
-                            dL_dopacity, scales ? dL_dscales : nullptr, scales ? dL_drotations : nullptr, dL_dcov3D, s);
+  {
+    ProfScope ps(3, s);
+    u3d_launch_render_bwd(d, b, bg, dL_dcolor, dL_dinvdepth, acc, s);
+  }
+  {
+    ProfScope ps(4, s);
+    u3d_launch_preprocess_bwd(d, b, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
+                              projmatrix, campos, radii, acc, dL_dmeans3D, dL_dmeans2D, shs ? dL_dshs : nullptr, dL_dcolors,
+                              dL_dopacity, scales ? dL_dscales : nullptr, scales ? dL_drotations : nullptr, dL_dcov3D, s);
+  }
   return finish(desc, s);
 }
 
@@ -137,6 +175,37 @@ int u3d_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
   if (!means3D || !viewmatrix || !present) return U3D_ERR_INVALID_ARGUMENT;
   u3d_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
+}
+
+int u3d_profile_begin(int32_t max_records) {
+  if (g_prof_on || max_records <= 0) return U3D_ERR_INVALID_ARGUMENT;
+  g_prof.resize((size_t)max_records);
+  for (auto& r : g_prof) {
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return U3D_ERR_NO_DEVICE;
+  }
+  g_prof_used = 0;
+  g_prof_on = true;
+  return U3D_OK;
+}
+
+int u3d_profile_end(float* ms, int32_t* count) {
+  if (!g_prof_on || !ms || !count) return U3D_ERR_INVALID_ARGUMENT;
+  g_prof_on = false;
+  for (int k = 0; k < U3D_PROFILE_KINDS; ++k) { ms[k] = 0.f; count[k] = 0; }
+  int rc = U3D_OK;
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    float t = 0.f;
+    if (hipEventSynchronize(g_prof[i].b) != hipSuccess || hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) {
+      rc = U3D_ERR_LAUNCH;
+      continue;
+    }
+    ms[g_prof[i].kind] += t;
+    count[g_prof[i].kind] += 1;
+  }
+  for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof.clear();
+  g_prof_used = 0;
+  return rc;
 }
 
 }  // extern "C"

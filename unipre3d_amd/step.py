@@ -1,0 +1,49 @@
+"""One render-loss training step (SURVEY.md R1 -> R7/R2/R4 -> R8 -> R5): the hot loop of
+Trainer.train_iteration (train_network.py:450-464) from the head output onward, with the per-object /
+per-view Python loop replaced by one batched operator call."""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import head as head_mod
+from . import losses
+from .synthetic import SyntheticBatch
+
+
+def render_loss_forward(raw: torch.Tensor, batch: SyntheticBatch, H: int, W: int, input_images: int = 0,
+                        loss_kind: str = "focal_l2", render_fn: Optional[Callable] = None, max_sh_degree: int = 1):
+    """raw (B,23,P) head output -> (loss, rendered (B*V,3,H,W)).  `render_fn` defaults to the HIP batched
+    renderer; tests may inject another differentiable renderer with the same signature."""
+    if render_fn is None:
+        from .renderer import render_views as render_fn
+    if batch.level == "object":
+        g = head_mod.process_object_output(raw, batch.center, batch.offset_scale, max_sh_degree)
+    else:
+        B, C, P = raw.shape
+        flat = raw.permute(0, 2, 1).reshape(B * P, C)
+        idx = torch.arange(B, device=raw.device).repeat_interleave(P)[:, None]
+        lists = head_mod.process_scene_output(flat, batch.center.reshape(B * P, 3), idx, batch.offset_scale, max_sh_degree)
+        g = {k: torch.stack(v) for k, v in lists.items()}
+    rendered = render_fn(g, batch.world_view, batch.full_proj, batch.camera_center, batch.bg, batch.fov_deg, H, W,
+                         input_images=input_images, max_sh_degree=max_sh_degree)
+    gt = batch.gt[:, input_images:].reshape(-1, 3, H, W)
+    white = bool(batch.bg[0].item() > 0.5) if loss_kind == "focal_l2" else False
+    loss = losses.render_loss(rendered, gt, loss_kind, white_background=white)
+    return loss, rendered
+
+
+def train_step(model: torch.nn.Module, feats: torch.Tensor, batch: SyntheticBatch, optimizer: torch.optim.Optimizer, H: int,
+               W: int, input_images: int = 0, loss_kind: str = "focal_l2", render_fn: Optional[Callable] = None,
+               clip_grad: Optional[float] = 1.0) -> torch.Tensor:
+    """zero_grad -> head -> render-loss -> backward (DDP all-reduce inside) -> clip -> optimizer step
+    (train_network.py:329-352 without the per-parameter NaN scan's host syncs)."""
+    optimizer.zero_grad(set_to_none=True)
+    raw = model(feats)
+    loss, _ = render_loss_forward(raw, batch, H, W, input_images, loss_kind, render_fn)
+    loss.backward()
+    if clip_grad is not None:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip_grad)
+    optimizer.step()
+    return loss.detach()
