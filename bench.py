@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C2", choices=sorted(synthetic.CONFIGS))
     ap.add_argument("--compact", action="store_true", help="secondary compact-splat regime (SURVEY 8d)")
+    ap.add_argument("--unfused", action="store_true", help="torch activations + torch loss around the batched operator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     a = ap.parse_args()
@@ -109,7 +110,7 @@ def main():
     loss_kind = "focal_l2" if level == "object" else "l2"
 
     def one_step():
-        return step.train_step(model, feats, batch, opt, H, W, 0, loss_kind)
+        return step.train_step(model, feats, batch, opt, H, W, 0, loss_kind, fused=not a.unfused)
 
     for _ in range(a.warmup):
         one_step()
@@ -165,7 +166,8 @@ def main():
             "config": {"workload": f"{a.config}: render-loss step, {level}-level, P={P} Gaussians/object, {H}x{W}, "
                                    f"B={B}/GPU x V={V} views = {NV} renders/GPU/step" + (" (compact splats)" if a.compact else ""),
                        "global_batch": B * world, "views_per_step": NV * world, "parallelism": f"dp{world}",
-                       "loss": loss_kind, "num_rendered_per_view": R_mean},
+                       "loss": loss_kind, "num_rendered_per_view": R_mean,
+                       "path": "unfused (torch activations/loss)" if a.unfused else "fused head-activation + render + loss (HIP)"},
             "render_loss_step_ms": {"rasterizer_fwd_kernels": fwd_ms, "rasterizer_bwd_kernels": bwd_ms, "kernels": kernels},
             "final_loss": float(loss),
         }

@@ -70,7 +70,23 @@ typedef struct u3d_scratch_sizes {
   size_t image_bytes;    /* per-pixel final transmittance + last contributor ("imgBuffer")    */
   size_t backward_bytes; /* per (view, Gaussian) screen-space gradient accumulators           */
   size_t num_rendered_offset; /* byte offset inside geom of uint32 num_rendered[n_views]      */
+  size_t fused_bytes;    /* u3d_render_loss_*: quaternion norms/dots + per-tile loss partials  */
 } u3d_scratch_sizes;
+
+/* Gaussian head layout for the fused entry points (model/gaussian_predictor.py:174-181, 249-254). */
+typedef struct u3d_head_desc {
+  int32_t mode;        /* 1 = object level (quaternions normalised ACROSS THE SET'S POINTS, the reference's
+                          F.normalize on (B,4,N), :254,:318), 2 = scene level (per quaternion, :347-349) */
+  int32_t channels;    /* C = 11 + 3*(D+1)^2: xyz 3 | opacity 1 | scaling 3 | rotation 4 | SH 3*(D+1)^2 */
+  float offset_scale;  /* cfg.model.offset_scale                                                         */
+} u3d_head_desc;
+
+/* Render loss fused into the rasterizer (utils/loss_utils.py:17-45 via train_network.py:260-302). */
+typedef struct u3d_loss_desc {
+  int32_t kind;                  /* 1 = l2, 2 = focal_l2, 3 = l1                                   */
+  float non_bg_color_loss_rate;  /* focal_l2 only (configs/transformer_pretraining.yaml:31-32: 4, 1) */
+  float bg_color_loss_rate;
+} u3d_loss_desc;
 
 int u3d_abi_version(void);
 const char* u3d_error_string(int code);
@@ -121,6 +137,32 @@ int u3d_rasterize_backward(const u3d_raster_desc* desc, const float* bg, const f
                            const void* binning, const void* image, void* backward_scratch, float* dL_dmeans3D,
                            float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors, float* dL_dopacity,
                            float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* stream);
+
+/*
+ * Fused render-loss step (SURVEY.md N2 + N3): everything between the Gaussian head's Linear output and the
+ * scalar loss in ONE launch sequence -- replaces, for all B objects x V views of a step,
+ *   model/gaussian_predictor.py:279-328 (activations), gaussian_renderer/__init__.py:78-97 (SH concat + operator),
+ *   train_network.py:418-446 (per-object / per-view loop, torch.stack) and utils/loss_utils.py:17-45 (loss).
+ *   head_out [n_items][P][C]  raw head output, point-major (the contiguous result of `final`, before the permute
+ *                             of model/point_predictor.py:100)
+ *   center   [n_items][P][3]  point centres added to tanh(xyz)*offset_scale
+ *   gt       [n_views][3][H][W]
+ * outputs: out_color [n_views][3][H][W] (kept: the backward reads it), radii, loss_out[1] = mean loss.
+ * The loss value is reduced in a fixed order (deterministic).  `bg` is both the render background and the
+ * colour focal_l2 compares gt against (train_network.py:270-283 uses the same tensor for both).
+ */
+int u3d_render_loss_forward(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss,
+                            const float* bg, const float* head_out, const float* center, const float* viewmatrix,
+                            const float* projmatrix, const float* campos, const float* gt, float* out_color,
+                            int32_t* radii, float* loss_out, void* geom, void* binning, void* image, void* fused,
+                            void* stream);
+
+/* Backward of the fused step: d_head_out [n_items][P][C] = dL/d(head_out) * dloss[0] (dloss: device scalar). */
+int u3d_render_loss_backward(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss,
+                             const float* bg, const float* head_out, const float* center, const float* viewmatrix,
+                             const float* projmatrix, const float* campos, const float* gt, const int32_t* radii,
+                             const float* out_color, const float* dloss, const void* geom, const void* binning,
+                             const void* image, void* fused, void* backward_scratch, float* d_head_out, void* stream);
 
 /* Frustum test only: replaces `_C.mark_visible` (no caller in the reference tree). present[P] = z_view > 0.2 */
 int u3d_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -122,3 +122,28 @@ def test_full_size_C2_properties(oracle_mod):
                                b.full_proj[bi, v].numpy(), b.camera_center[bi, v].numpy(), b.bg.numpy(), 256, 256, t, t,
                                shs=shs, scales=gc["scaling"][bi].numpy(), rotations=gc["rotation"][bi].numpy(), sh_degree=1)
         assert rel_l2(out[bi * 4 + v].detach().cpu().numpy(), r.color) < TOL
+
+
+@pytest.mark.parametrize("level,loss_kind,P,V,H,W", [("object", "focal_l2", 128, 4, 128, 128), ("object", "l2", 300, 2, 64, 96),
+                                                      ("scene", "l2", 500, 3, 120, 160), ("object", "l1", 64, 2, 48, 48)])
+def test_fused_render_loss_equals_unfused_path(level, loss_kind, P, V, H, W):
+    """N2+N3: head-activation + render + loss in the HIP library == torch activations + batched operator + torch loss,
+    for the loss value and for the gradient w.r.t. the raw head output."""
+    from unipre3d_amd import fused, step
+    b, bd = _batch(2, P, V, H, W, level=level, seed=11)
+    head_out = bd.raw.permute(0, 2, 1).contiguous().requires_grad_(True)      # (B,P,23): what `final` emits
+    loss_f, img_f, radii_f = fused.render_loss_fused(head_out, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt,
+                                                     bd.bg, bd.fov_deg, H, W, level=level, offset_scale=bd.offset_scale,
+                                                     loss_kind=loss_kind, debug=True)
+    (3.0 * loss_f).backward()
+    g_fused = head_out.grad.clone()
+    raw = bd.raw.clone().requires_grad_(True)                                  # (B,23,P) view the reference works on
+    loss_u, img_u = step.render_loss_forward(raw, bd, H, W, 0, loss_kind)
+    (3.0 * loss_u).backward()
+    g_unfused = raw.grad.permute(0, 2, 1)
+    assert rel_l2(img_f.cpu().numpy(), img_u.detach().cpu().numpy()) < 1e-5
+    assert abs(loss_f.item() - loss_u.item()) < 1e-5 * max(1.0, abs(loss_u.item()))
+    assert rel_l2(g_fused.cpu().numpy(), g_unfused.cpu().numpy()) < TOL
+    # every channel group carries gradient (xyz, opacity, scaling, rotation, dc, rest)
+    for lo, hi in ((0, 3), (3, 4), (4, 7), (7, 11), (11, 14), (14, 23)):
+        assert g_fused[..., lo:hi].abs().sum().item() > 0

@@ -20,7 +20,8 @@ CSRC = os.path.join(_HERE, "csrc")
 FLAG_PREFILTERED, FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_EXACT_AA_GRAD = 1, 2, 4, 8
 
 EXPORTS = ("u3d_abi_version", "u3d_error_string", "u3d_scratch_query", "u3d_rasterize_forward",
-           "u3d_rasterize_backward", "u3d_mark_visible", "u3d_profile_begin", "u3d_profile_end")
+           "u3d_rasterize_backward", "u3d_mark_visible", "u3d_profile_begin", "u3d_profile_end",
+           "u3d_render_loss_forward", "u3d_render_loss_backward")
 PROFILE_KINDS = ("preprocess_fwd", "depth_sort", "render_fwd", "render_bwd", "preprocess_bwd")
 
 
@@ -33,7 +34,20 @@ class RasterDesc(ctypes.Structure):
 
 class ScratchSizes(ctypes.Structure):
     _fields_ = [("geom_bytes", ctypes.c_size_t), ("binning_bytes", ctypes.c_size_t), ("image_bytes", ctypes.c_size_t),
-                ("backward_bytes", ctypes.c_size_t), ("num_rendered_offset", ctypes.c_size_t)]
+                ("backward_bytes", ctypes.c_size_t), ("num_rendered_offset", ctypes.c_size_t),
+                ("fused_bytes", ctypes.c_size_t)]
+
+
+class HeadDesc(ctypes.Structure):
+    _fields_ = [("mode", ctypes.c_int32), ("channels", ctypes.c_int32), ("offset_scale", ctypes.c_float)]
+
+
+class LossDesc(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("non_bg_color_loss_rate", ctypes.c_float),
+                ("bg_color_loss_rate", ctypes.c_float)]
+
+
+LOSS_KINDS = {"l2": 1, "focal_l2": 2, "l1": 3}
 
 
 def build(verbose: bool = False) -> str:
@@ -71,6 +85,10 @@ def load() -> ctypes.CDLL:
     lib.u3d_rasterize_backward.argtypes = [ctypes.POINTER(RasterDesc)] + [vp] * 27
     lib.u3d_mark_visible.restype = ctypes.c_int
     lib.u3d_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.u3d_render_loss_forward.restype = ctypes.c_int
+    lib.u3d_render_loss_forward.argtypes = [ctypes.POINTER(RasterDesc), ctypes.POINTER(HeadDesc), ctypes.POINTER(LossDesc)] + [vp] * 15
+    lib.u3d_render_loss_backward.restype = ctypes.c_int
+    lib.u3d_render_loss_backward.argtypes = [ctypes.POINTER(RasterDesc), ctypes.POINTER(HeadDesc), ctypes.POINTER(LossDesc)] + [vp] * 17
     lib.u3d_profile_begin.restype = ctypes.c_int
     lib.u3d_profile_begin.argtypes = [i32]
     lib.u3d_profile_end.restype = ctypes.c_int

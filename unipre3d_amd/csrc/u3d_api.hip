@@ -41,6 +41,63 @@ int check_desc(const u3d_raster_desc* d) {
   return U3D_OK;
 }
 
+U3DSource plain_source(const u3d_raster_desc& d, const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp) {
+  U3DSource src{};
+  src.means = means3D; src.s_means = 3;
+  src.shs = shs; src.s_shs = d.sh_coeffs * 3;
+  src.colors = colors_precomp;
+  src.opac = opacities; src.s_opac = 1;
+  src.scales = scales; src.s_scales = 3;
+  src.rots = rotations; src.s_rots = 4;
+  src.cov = cov3D_precomp;
+  src.act = 0;
+  return src;
+}
+
+U3DSource head_source(const u3d_raster_desc& d, const u3d_head_desc& h, const float* head_out, const float* center,
+                      const float* qnorm) {
+  U3DSource src{};
+  const int C = h.channels;
+  src.means = head_out; src.s_means = C;
+  src.opac = head_out + 3; src.s_opac = C;
+  src.scales = head_out + 4; src.s_scales = C;
+  src.rots = head_out + 7; src.s_rots = C;
+  src.shs = head_out + 11; src.s_shs = C;
+  src.colors = nullptr; src.cov = nullptr;
+  src.act = h.mode;
+  src.center = center;
+  src.offset_scale = h.offset_scale;
+  src.qnorm = qnorm;
+  (void)d;
+  return src;
+}
+
+int check_fused(const u3d_raster_desc* d, const u3d_head_desc* h, const u3d_loss_desc* l) {
+  int rc = check_desc(d);
+  if (rc != U3D_OK) return rc;
+  if (!h || !l) return U3D_ERR_INVALID_ARGUMENT;
+  if (h->mode != 1 && h->mode != 2) return U3D_ERR_INVALID_ARGUMENT;
+  const int K = (d->sh_degree + 1) * (d->sh_degree + 1);
+  if (h->channels != 11 + 3 * K || d->sh_coeffs != K) return U3D_ERR_INVALID_ARGUMENT;
+  if (l->kind < 1 || l->kind > 3) return U3D_ERR_INVALID_ARGUMENT;
+  if (l->kind == 2 && !(l->non_bg_color_loss_rate + l->bg_color_loss_rate > 0.f)) return U3D_ERR_INVALID_ARGUMENT;
+  return U3D_OK;
+}
+
+U3DLoss make_loss(const u3d_raster_desc& d, const u3d_loss_desc& l, const float* gt, float* partial, const float* dloss) {
+  U3DLoss L{};
+  L.kind = l.kind;
+  L.gt = gt;
+  const float sum = l.bg_color_loss_rate + l.non_bg_color_loss_rate;
+  L.w_bg = l.kind == 2 ? 2.f * l.bg_color_loss_rate / sum : 1.f;
+  L.w_non = l.kind == 2 ? 2.f * l.non_bg_color_loss_rate / sum : 1.f;
+  L.inv_count = (float)(1.0 / ((double)d.n_items * d.views_per_item * 3.0 * d.image_height * d.image_width));
+  L.partial = partial;
+  L.dloss = dloss;
+  return L;
+}
+
 int finish(const u3d_raster_desc* d, hipStream_t s) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -83,6 +140,7 @@ int u3d_scratch_query(const u3d_raster_desc* desc, u3d_scratch_sizes* out) {
   out->image_bytes = L.image_bytes;
   out->backward_bytes = L.backward_bytes;
   out->num_rendered_offset = L.num_rendered_offset;
+  out->fused_bytes = L.fused_bytes;
   return U3D_OK;
 }
 
@@ -113,7 +171,7 @@ int u3d_rasterize_forward(const u3d_raster_desc* desc, const float* bg, const fl
   if (d.P > 0) {
     {
       ProfScope ps(0, s);
-      u3d_launch_preprocess_fwd(d, b, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+      u3d_launch_preprocess_fwd(d, b, plain_source(d, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp),
                                 viewmatrix, projmatrix, campos, radii, s);
     }
     {
@@ -123,7 +181,7 @@ int u3d_rasterize_forward(const u3d_raster_desc* desc, const float* bg, const fl
   }
   {
     ProfScope ps(2, s);
-    u3d_launch_render_fwd(d, b, bg, out_color, out_invdepth, s);
+    u3d_launch_render_fwd(d, b, bg, out_color, out_invdepth, U3DLoss{}, s);
   }
   return finish(desc, s);
 }
@@ -156,14 +214,95 @@ int u3d_rasterize_backward(const u3d_raster_desc* desc, const float* bg, const f
   (void)hipMemsetAsync(acc, 0, L.backward_bytes, s);
   {
     ProfScope ps(3, s);
-    u3d_launch_render_bwd(d, b, bg, dL_dcolor, dL_dinvdepth, acc, s);
+    u3d_launch_render_bwd(d, b, bg, dL_dcolor, dL_dinvdepth, nullptr, U3DLoss{}, acc, s);
   }
   {
     ProfScope ps(4, s);
-    u3d_launch_preprocess_bwd(d, b, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
-                              projmatrix, campos, radii, acc, dL_dmeans3D, dL_dmeans2D, shs ? dL_dshs : nullptr, dL_dcolors,
-                              dL_dopacity, scales ? dL_dscales : nullptr, scales ? dL_drotations : nullptr, dL_dcov3D, s);
+    U3DGradSink sink{};
+    sink.means = dL_dmeans3D; sink.shs = shs ? dL_dshs : nullptr; sink.colors = dL_dcolors; sink.opac = dL_dopacity;
+    sink.scales = scales ? dL_dscales : nullptr; sink.rots = scales ? dL_drotations : nullptr; sink.cov = dL_dcov3D;
+    sink.means2D = dL_dmeans2D; sink.qdot = nullptr;
+    u3d_launch_preprocess_bwd(d, b, plain_source(d, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp),
+                              viewmatrix, projmatrix, campos, radii, acc, sink, s);
   }
+  return finish(desc, s);
+}
+
+int u3d_render_loss_forward(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss,
+                            const float* bg, const float* head_out, const float* center, const float* viewmatrix,
+                            const float* projmatrix, const float* campos, const float* gt, float* out_color,
+                            int32_t* radii, float* loss_out, void* geom, void* binning, void* image, void* fused,
+                            void* stream) {
+  int rc = check_fused(desc, head, loss);
+  if (rc != U3D_OK) return rc;
+  const u3d_raster_desc& d = *desc;
+  const int NV = d.n_items * d.views_per_item;
+  if (NV == 0 || d.P == 0) return U3D_ERR_INVALID_ARGUMENT;
+  if (!bg || !head_out || !center || !viewmatrix || !projmatrix || !campos || !gt || !out_color || !radii || !loss_out ||
+      !geom || !binning || !image || !fused)
+    return U3D_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  U3DBuffers b{};
+  u3d_carve(d, geom, binning, image, &b);
+  U3DFused f{};
+  u3d_carve_fused(d, fused, &f);
+  (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
+  (void)hipMemsetAsync(b.n_vis, 0, sizeof(uint32_t) * NV, s);
+  if (head->mode == 1) u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, s);
+  {
+    ProfScope ps(0, s);
+    u3d_launch_preprocess_fwd(d, b, head_source(d, *head, head_out, center, f.qnorm), viewmatrix, projmatrix, campos, radii, s);
+  }
+  {
+    ProfScope ps(1, s);
+    u3d_launch_depth_sort(d, b, radii, s);
+  }
+  const int T = ((d.image_width + U3D_TILE - 1) / U3D_TILE) * ((d.image_height + U3D_TILE - 1) / U3D_TILE);
+  const U3DLoss L = make_loss(d, *loss, gt, f.partial, nullptr);
+  {
+    ProfScope ps(2, s);
+    u3d_launch_render_fwd(d, b, bg, out_color, nullptr, L, s);
+  }
+  u3d_launch_loss_reduce(NV * T, f.partial, L.inv_count, loss_out, s);
+  return finish(desc, s);
+}
+
+int u3d_render_loss_backward(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss,
+                             const float* bg, const float* head_out, const float* center, const float* viewmatrix,
+                             const float* projmatrix, const float* campos, const float* gt, const int32_t* radii,
+                             const float* out_color, const float* dloss, const void* geom, const void* binning,
+                             const void* image, void* fused, void* backward_scratch, float* d_head_out, void* stream) {
+  int rc = check_fused(desc, head, loss);
+  if (rc != U3D_OK) return rc;
+  const u3d_raster_desc& d = *desc;
+  const int NV = d.n_items * d.views_per_item;
+  if (NV == 0 || d.P == 0) return U3D_ERR_INVALID_ARGUMENT;
+  if (!bg || !head_out || !center || !viewmatrix || !projmatrix || !campos || !gt || !radii || !out_color || !dloss ||
+      !geom || !binning || !image || !fused || !backward_scratch || !d_head_out)
+    return U3D_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  U3DBuffers b{};
+  const U3DLayout Lay = u3d_carve(d, (void*)geom, (void*)binning, (void*)image, &b);
+  U3DFused f{};
+  u3d_carve_fused(d, fused, &f);
+  float* acc = (float*)backward_scratch;
+  (void)hipMemsetAsync(acc, 0, Lay.backward_bytes, s);
+  (void)hipMemsetAsync(f.qdot, 0, sizeof(float) * 4 * d.n_items, s);
+  const U3DLoss L = make_loss(d, *loss, gt, f.partial, dloss);
+  {
+    ProfScope ps(3, s);
+    u3d_launch_render_bwd(d, b, bg, nullptr, nullptr, out_color, L, acc, s);
+  }
+  const int C = head->channels;
+  U3DGradSink sink{};
+  sink.means = d_head_out; sink.opac = d_head_out + 3; sink.scales = d_head_out + 4; sink.rots = d_head_out + 7;
+  sink.shs = d_head_out + 11; sink.colors = nullptr; sink.cov = nullptr; sink.means2D = nullptr; sink.qdot = f.qdot;
+  {
+    ProfScope ps(4, s);
+    u3d_launch_preprocess_bwd(d, b, head_source(d, *head, head_out, center, f.qnorm), viewmatrix, projmatrix, campos, radii,
+                              acc, sink, s);
+  }
+  if (head->mode == 1) u3d_launch_quat_fixup(d.n_items, d.P, head_out + 7, C, f.qnorm, f.qdot, d_head_out + 7, s);
   return finish(desc, s);
 }
 

@@ -33,9 +33,65 @@ struct U3DBuffers {
   uint32_t* n_contrib;   // [NV*H*W]  sorted position + 1 of the last contributor
 };
 
-struct U3DLayout {
-  size_t geom_bytes, binning_bytes, image_bytes, backward_bytes, num_rendered_offset;
+// Where the per-Gaussian parameters of set `item`, Gaussian `i` come from.
+//  act == 0: the operator's own tensors (means3D [P][3], shs [P][M][3], ...), strides are the natural ones.
+//  act == 1/2: the Gaussian head's raw output record (model/gaussian_predictor.py:174-181 split
+//  [3,1,3,4,3,9] = xyz, opacity, scaling, rotation, features_dc, features_rest), activations of
+//  model/gaussian_predictor.py:249-254 applied in-kernel:
+//     xyz = tanh(raw)*offset_scale + center, opacity = sigmoid, scale = exp(clamp(raw,-1,20)),
+//     rotation = raw / max(norm, 1e-6) with norm taken ACROSS THE SET'S POINTS per component (act 1, the
+//     reference's object-level quirk, R1) or per quaternion (act 2, scene level); SH = raw[11:11+3K].
+struct U3DSource {
+  const float* means;   int s_means;    // element stride between consecutive Gaussians
+  const float* shs;     int s_shs;
+  const float* colors;  // [P][3] precomputed colours or null
+  const float* opac;    int s_opac;
+  const float* scales;  int s_scales;
+  const float* rots;    int s_rots;
+  const float* cov;     // [P][6] or null
+  int act;              // 0 none, 1 object-level head, 2 scene-level head
+  const float* center;  // [B][P][3] (act != 0)
+  float offset_scale;
+  const float* qnorm;   // [B][4] across-point quaternion column norms (act == 1)
 };
+
+// Where per-Gaussian gradients go (same strides as the source; act != 0 chains through the activations).
+struct U3DGradSink {
+  float* means; float* shs; float* colors; float* opac; float* scales; float* rots; float* cov;
+  float* means2D;       // [NV][P][3] or null
+  float* qdot;          // [B][4] sum_i raw_rot[i][c] * g[i][c]  (act == 1; finished by u3d_quat_fixup)
+};
+
+// Optional fused render loss: utils/loss_utils.py:17-45 evaluated in the render epilogue /
+// backward prologue.  kind 0 = none, 1 = l2, 2 = focal_l2, 3 = l1.
+struct U3DLoss {
+  int kind;
+  const float* gt;        // [NV][3][H][W]
+  float w_bg, w_non;      // normalised focal weights 2*bg/(bg+non), 2*non/(bg+non)
+  float inv_count;        // 1 / (NV*3*H*W)
+  float* partial;         // [NV*T] per-tile partial sums (forward)
+  const float* dloss;     // device scalar dL/dloss (backward)
+};
+
+struct U3DLayout {
+  size_t geom_bytes, binning_bytes, image_bytes, backward_bytes, num_rendered_offset, fused_bytes;
+};
+
+// fused scratch: [qnorm n_items*4][qdot n_items*4][loss partial NV*T]
+struct U3DFused {
+  float* qnorm; float* qdot; float* partial;
+};
+static inline size_t u3d_carve_fused(const u3d_raster_desc& d, void* base, U3DFused* f) {
+  const size_t NV = (size_t)d.n_items * d.views_per_item;
+  const size_t T = (size_t)((d.image_width + U3D_TILE - 1) / U3D_TILE) * ((d.image_height + U3D_TILE - 1) / U3D_TILE);
+  const size_t a = (((size_t)d.n_items * 4 * sizeof(float)) + 255) & ~(size_t)255;
+  if (f) {
+    f->qnorm = (float*)base;
+    f->qdot = (float*)((char*)base + a);
+    f->partial = (float*)((char*)base + 2 * a);
+  }
+  return 2 * a + (((NV * T * sizeof(float)) + 255) & ~(size_t)255) + 256;
+}
 
 static inline size_t u3d_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -83,26 +139,26 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
   L.image_bytes = o > 0 ? o : 256;
 #undef CARVE
   L.backward_bytes = u3d_align(sizeof(float) * U3D_NACC * (NG > 0 ? NG : 1));
+  L.fused_bytes = u3d_carve_fused(d, nullptr, nullptr);
   return L;
 }
 
 // launchers (one per translation unit)
-void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* means3D, const float* shs,
-                               const float* colors_precomp, const float* opacities, const float* scales,
-                               const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, int32_t* radii, hipStream_t s);
-void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* means3D, const float* shs,
-                               const float* colors_precomp, const float* opacities, const float* scales,
-                               const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
-                               const float* projmatrix, const float* campos, const int32_t* radii,
-                               const float* acc, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
-                               float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
-                               float* dL_dcov3D, hipStream_t s);
+void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
+                               const float* projmatrix, const float* campos, const int32_t* radii, const float* acc,
+                               const U3DGradSink& sink, hipStream_t s);
+void u3d_launch_quat_norms(int n_items, int P, const float* rots, int s_rots, float* qnorm, hipStream_t s);
+void u3d_launch_quat_fixup(int n_items, int P, const float* rots, int s_rots, const float* qnorm, const float* qdot,
+                           float* d_rots, hipStream_t s);
 void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const int32_t* radii, hipStream_t s);
 void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,
-                           float* out_invdepth, hipStream_t s);
+                           float* out_invdepth, const U3DLoss& loss, hipStream_t s);
 void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, const float* dL_dcolor,
-                           const float* dL_dinvdepth, float* acc, hipStream_t s);
+                           const float* dL_dinvdepth, const float* out_color, const U3DLoss& loss, float* acc,
+                           hipStream_t s);
+void u3d_launch_loss_reduce(int n, const float* partial, float inv_count, float* loss_out, hipStream_t s);
 
 #ifdef __HIPCC__
 // ---- device helpers -------------------------------------------------------------------------

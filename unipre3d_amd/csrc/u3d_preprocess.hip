@@ -121,11 +121,49 @@ __device__ __forceinline__ void sh_to_rgb(const float* __restrict__ sh /* [M][3]
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ---------------------------------------------------------------------------------------------
+// Loads Gaussian (item, i) and applies the head activations when src.act != 0 (see U3DSource).
+struct GaussIn {
+  float p[3], op, s[3], q[4];
+  float th[3];      // tanh(raw xyz)            (act != 0)
+  float raw_s[3];   // raw scaling               (act != 0)
+  float raw_q[4];   // raw rotation              (act != 0)
+  float qn[4];      // normalisation denominators (act != 0)
+};
+
+__device__ __forceinline__ void load_gaussian(const U3DSource& src, int item, size_t gi, GaussIn& g) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g.p[k] = src.means[gi * src.s_means + k];
+  g.op = src.opac[gi * src.s_opac];
+  if (src.scales) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g.s[k] = src.scales[gi * src.s_scales + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g.q[k] = src.rots[gi * src.s_rots + k];
+  } else {
+    g.s[0] = g.s[1] = g.s[2] = 0.f; g.q[0] = g.q[1] = g.q[2] = g.q[3] = 0.f;
+  }
+  if (src.act != 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      g.th[k] = tanhf(g.p[k]);
+      g.p[k] = g.th[k] * src.offset_scale + src.center[gi * 3 + k];
+      g.raw_s[k] = g.s[k];
+      g.s[k] = expf(fminf(fmaxf(g.s[k], -1.f), 20.f));
+    }
+    g.op = 1.f / (1.f + expf(-g.op));
+    float n4 = sqrtf(g.q[0] * g.q[0] + g.q[1] * g.q[1] + g.q[2] * g.q[2] + g.q[3] * g.q[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g.raw_q[k] = g.q[k];
+      g.qn[k] = fmaxf(src.act == 1 ? src.qnorm[item * 4 + k] : n4, 1e-6f);
+      g.q[k] = g.q[k] / g.qn[k];
+    }
+  }
+}
+
 template <int D>
 __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
-    int P, int vpi, int M, int H, int W, float tanx, float tany, float mod, int flags, const float* __restrict__ means3D,
-    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
-    const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+    int P, int vpi, int H, int W, float tanx, float tany, float mod, int flags, U3DSource src,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     int32_t* __restrict__ radii, float* __restrict__ depth, float2* __restrict__ xy, float4* __restrict__ conic_op,
     float4* __restrict__ rgbd, uint2* __restrict__ rect, uint32_t* __restrict__ clamped,
@@ -135,10 +173,13 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
   uint32_t touched = 0;
   if (i < P) {
     const size_t g = (size_t)view * P + i;
-    const size_t gi = (size_t)(view / vpi) * P + i;
+    const int item = view / vpi;
+    const size_t gi = (size_t)item * P + i;
     Cam cam;
     load_cam(cam, viewmatrix, projmatrix, campos, view);
-    const float p[3] = {means3D[gi * 3], means3D[gi * 3 + 1], means3D[gi * 3 + 2]};
+    GaussIn gin;
+    load_gaussian(src, item, gi, gin);
+    const float* p = gin.p;
     int radius = 0;
     float zv = cam.V[2] * p[0] + cam.V[6] * p[1] + cam.V[10] * p[2] + cam.V[14];
     float2 pix = make_float2(0.f, 0.f);
@@ -151,13 +192,11 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
       for (int j = 0; j < 4; ++j) hom[j] = cam.Pm[j] * p[0] + cam.Pm[4 + j] * p[1] + cam.Pm[8 + j] * p[2] + cam.Pm[12 + j];
       const float p_w = 1.0f / (hom[3] + 0.0000001f);
       float c6[6];
-      if (cov3D_precomp) {
+      if (src.cov) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[gi * 6 + k];
+        for (int k = 0; k < 6; ++k) c6[k] = src.cov[gi * 6 + k];
       } else {
-        const float s[3] = {scales[gi * 3], scales[gi * 3 + 1], scales[gi * 3 + 2]};
-        const float q[4] = {rotations[gi * 4], rotations[gi * 4 + 1], rotations[gi * 4 + 2], rotations[gi * 4 + 3]};
-        cov3d_from_scale_rot(s, mod, q, c6);
+        cov3d_from_scale_rot(gin.s, mod, gin.q, c6);
       }
       const float fx = (float)W / (2.f * tanx), fy = (float)H / (2.f * tany);
       Ewa e;
@@ -185,18 +224,18 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
         const int nt = (x1 - x0) * (y1 - y0);
         if (nt > 0) {
           float rgb[3];
-          if (colors_precomp) {
-            rgb[0] = colors_precomp[gi * 3]; rgb[1] = colors_precomp[gi * 3 + 1]; rgb[2] = colors_precomp[gi * 3 + 2];
+          if (src.colors) {
+            rgb[0] = src.colors[gi * 3]; rgb[1] = src.colors[gi * 3 + 1]; rgb[2] = src.colors[gi * 3 + 2];
           } else {
             float dir[3] = {p[0] - cam.pos[0], p[1] - cam.pos[1], p[2] - cam.pos[2]};
             const float inv = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
             dir[0] *= inv; dir[1] *= inv; dir[2] *= inv;
-            sh_to_rgb<D>(shs + gi * (size_t)M * 3, dir, rgb, cb);
+            sh_to_rgb<D>(src.shs + gi * (size_t)src.s_shs, dir, rgb, cb);
           }
           radius = r;
           touched = (uint32_t)nt;
           pix = make_float2(px, py);
-          co = make_float4(abc[2] * det_inv, -abc[1] * det_inv, abc[0] * det_inv, opacities[gi] * aa);
+          co = make_float4(abc[2] * det_inv, -abc[1] * det_inv, abc[0] * det_inv, gin.op * aa);
           col = make_float4(rgb[0], rgb[1], rgb[2], zv);
           rc = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
         }
@@ -219,32 +258,30 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
 // ---------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
-    int P, int vpi, int M, int H, int W, float tanx, float tany, float mod, int flags, size_t NG,
-    const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ opacities,
-    const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+    int P, int vpi, int M, int H, int W, float tanx, float tany, float mod, int flags, size_t NG, U3DSource src,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const float* __restrict__ acc,
-    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs,
-    float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales,
-    float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D) {
+    U3DGradSink sink) {
+  __shared__ float s_qdot[4][4];
   const int item = blockIdx.y;
   const int i = blockIdx.x * U3D_BLOCK + threadIdx.x;
-  if (i >= P) return;
-  const size_t gi = (size_t)item * P + i;
-  const float p[3] = {means3D[gi * 3], means3D[gi * 3 + 1], means3D[gi * 3 + 2]};
+  const bool alive = i < P;
+  const size_t gi = (size_t)item * P + (alive ? i : 0);
+  GaussIn gin;
+  load_gaussian(src, item, gi, gin);
+  const float* p = gin.p;
+  const float* s = gin.s;
+  const float* q = gin.q;
+  const float* shs = src.shs;
+  float* dL_dmeans2D = sink.means2D;
   float c6[6];
-  float s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-  if (cov3D_precomp) {
+  if (src.cov) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[gi * 6 + k];
+    for (int k = 0; k < 6; ++k) c6[k] = src.cov[gi * 6 + k];
   } else {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) s[k] = scales[gi * 3 + k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) q[k] = rotations[gi * 4 + k];
     cov3d_from_scale_rot(s, mod, q, c6);
   }
-  const float op_in = opacities[gi];
+  const float op_in = gin.op;
   constexpr int K = (D + 1) * (D + 1);
   float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
   float dsh[K * 3];
@@ -252,7 +289,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
   for (int k = 0; k < K * 3; ++k) dsh[k] = 0.f;
   const float fx = (float)W / (2.f * tanx), fy = (float)H / (2.f * tany);
 
-  for (int vk = 0; vk < vpi; ++vk) {
+  for (int vk = 0; vk < (alive ? vpi : 0); ++vk) {
     const int view = item * vpi + vk;
     const size_t g = (size_t)view * P + i;
     const bool live = radii[g] > 0;
@@ -348,7 +385,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
       dmean[k] += (cam.Pm[k * 4] * m_w - cam.Pm[k * 4 + 3] * mul1) * a[0] + (cam.Pm[k * 4 + 1] * m_w - cam.Pm[k * 4 + 3] * mul2) * a[1];
     dcol[0] += a[6]; dcol[1] += a[7]; dcol[2] += a[8];
     if (shs) {
-      const float* sh = shs + gi * (size_t)M * 3;
+      const float* sh = shs + gi * (size_t)src.s_shs;
       const float dorig[3] = {p[0] - cam.pos[0], p[1] - cam.pos[1], p[2] - cam.pos[2]};
       const float sum2 = dorig[0] * dorig[0] + dorig[1] * dorig[1] + dorig[2] * dorig[2];
       const float inv = 1.f / sqrtf(sum2);
@@ -403,20 +440,9 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     }
   }
 
-  dL_dmeans3D[gi * 3] = dmean[0]; dL_dmeans3D[gi * 3 + 1] = dmean[1]; dL_dmeans3D[gi * 3 + 2] = dmean[2];
-  dL_dopacity[gi] = dop;
-  if (dL_dcolors) { dL_dcolors[gi * 3] = dcol[0]; dL_dcolors[gi * 3 + 1] = dcol[1]; dL_dcolors[gi * 3 + 2] = dcol[2]; }
-  if (dL_dcov3D) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) dL_dcov3D[gi * 6 + k] = dcov[k];
-  }
-  if (dL_dshs) {
-    float* o = dL_dshs + gi * (size_t)M * 3;
-#pragma unroll
-    for (int k = 0; k < K * 3; ++k) o[k] = dsh[k];
-    for (int k = K * 3; k < M * 3; ++k) o[k] = 0.f;
-  }
-  if (dL_dscales) {
+  // ---- outputs (strided like the source); act != 0 chains through the head activations ----
+  float drot[4] = {0.f, 0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f};
+  if (src.scales) {
     // Sigma = Mx Mx^T, Mx = R diag(mod*s): exact derivative of the un-normalised quaternion polynomial
     const float Gs[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
                          0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
@@ -438,13 +464,112 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
         ssum += dM * R[r_ * 3 + k];
         dR[r_ * 3 + k] = dM * sv[k];
       }
-      dL_dscales[gi * 3 + k] = mod * ssum;
+      dscale[k] = mod * ssum;
     }
     const float r = q[0], x = q[1], y = q[2], z = q[3];
-    dL_drotations[gi * 4 + 0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
-    dL_drotations[gi * 4 + 1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
-    dL_drotations[gi * 4 + 2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
-    dL_drotations[gi * 4 + 3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+    drot[0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+    drot[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
+    drot[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
+    drot[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+  }
+  float qd[4] = {0.f, 0.f, 0.f, 0.f};
+  if (alive) {
+    if (src.act != 0) {
+      // tanh, sigmoid, exp(clamp) derivatives (model/gaussian_predictor.py:249-254)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        dmean[k] *= src.offset_scale * (1.f - gin.th[k] * gin.th[k]);
+        dscale[k] *= (gin.raw_s[k] >= -1.f && gin.raw_s[k] <= 20.f) ? s[k] : 0.f;
+      }
+      dop *= op_in * (1.f - op_in);
+      if (src.act == 2) {
+        // per-quaternion normalise: d x_j = g_j / n - x_j (g . x) / n^3   (n > eps), g_j / eps otherwise
+        const float n2 = gin.raw_q[0] * gin.raw_q[0] + gin.raw_q[1] * gin.raw_q[1] + gin.raw_q[2] * gin.raw_q[2] + gin.raw_q[3] * gin.raw_q[3];
+        const float n = sqrtf(n2);
+        const float dot = drot[0] * gin.raw_q[0] + drot[1] * gin.raw_q[1] + drot[2] * gin.raw_q[2] + drot[3] * gin.raw_q[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) drot[k] = n > 1e-6f ? drot[k] / n - gin.raw_q[k] * dot / (n2 * n) : drot[k] / 1e-6f;
+      } else {
+        // across-point normalise (object level): first term here, the column dot product is reduced below and the
+        // second term is applied by quat_fixup_kernel
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { qd[k] = drot[k] * gin.raw_q[k]; drot[k] = drot[k] / gin.qn[k]; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sink.means[gi * src.s_means + k] = dmean[k];
+    sink.opac[gi * src.s_opac] = dop;
+    if (sink.colors) { sink.colors[gi * 3] = dcol[0]; sink.colors[gi * 3 + 1] = dcol[1]; sink.colors[gi * 3 + 2] = dcol[2]; }
+    if (sink.cov) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sink.cov[gi * 6 + k] = dcov[k];
+    }
+    if (sink.shs) {
+      float* o = sink.shs + gi * (size_t)src.s_shs;
+#pragma unroll
+      for (int k = 0; k < K * 3; ++k) o[k] = dsh[k];
+      for (int k = K * 3; k < M * 3; ++k) o[k] = 0.f;
+    }
+    if (sink.scales) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sink.scales[gi * src.s_scales + k] = dscale[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sink.rots[gi * src.s_rots + k] = drot[k];
+    }
+  }
+  if (src.act == 1) {
+    // block reduction of sum_i raw_q[i][c] * g[i][c]; one atomic per block and component
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = qd[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) s_qdot[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      const float v = s_qdot[0][threadIdx.x] + s_qdot[1][threadIdx.x] + s_qdot[2][threadIdx.x] + s_qdot[3][threadIdx.x];
+      unsafeAtomicAdd(&sink.qdot[item * 4 + threadIdx.x], v);
+    }
+  }
+}
+
+// across-point quaternion norms: qnorm[item][c] = || raw_rot[item, :, c] ||_2   (F.normalize(x(B,4,N), dim=-1))
+__global__ __launch_bounds__(U3D_BLOCK) void quat_norms_kernel(int P, const float* __restrict__ rots, int s_rots,
+                                                               float* __restrict__ qnorm) {
+  __shared__ float sm[4][4];
+  const int item = blockIdx.x;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < P; i += U3D_BLOCK) {
+    const float* r = rots + ((size_t)item * P + i) * s_rots;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] += r[k] * r[k];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float v = a[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) sm[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) qnorm[item * 4 + threadIdx.x] = sqrtf(sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+// second term of the across-point normalise backward: d x_i -= x_i * (sum_j x_j g_j) / n^3  when n > eps
+__global__ __launch_bounds__(U3D_BLOCK) void quat_fixup_kernel(int P, const float* __restrict__ rots, int s_rots,
+                                                               const float* __restrict__ qnorm, const float* __restrict__ qdot,
+                                                               float* __restrict__ d_rots) {
+  const int item = blockIdx.y;
+  const int i = blockIdx.x * U3D_BLOCK + threadIdx.x;
+  if (i >= P) return;
+  const size_t o = ((size_t)item * P + i) * s_rots;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float n = qnorm[item * 4 + k];
+    if (n > 1e-6f) d_rots[o + k] -= rots[o + k] * qdot[item * 4 + k] / (n * n * n);
   }
 }
 
@@ -458,18 +583,15 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 
 }  // namespace
 
-void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* means3D, const float* shs,
-                               const float* colors_precomp, const float* opacities, const float* scales,
-                               const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, int32_t* radii, hipStream_t s) {
   const int NV = d.n_items * d.views_per_item;
   dim3 grid((d.P + U3D_BLOCK - 1) / U3D_BLOCK, NV), block(U3D_BLOCK);
-  const int D = shs ? d.sh_degree : 0;
+  const int D = src.shs ? d.sh_degree : 0;
 #define LAUNCH(DEG)                                                                                                   \
-  hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, 0, s, d.P, d.views_per_item, d.sh_coeffs, d.image_height, \
-                     d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, means3D, shs, colors_precomp,    \
-                     opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, radii, b.depth, b.xy, \
-                     b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered)
+  hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, 0, s, d.P, d.views_per_item, d.image_height, d.image_width, \
+                     d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, src, viewmatrix, projmatrix, campos, radii, b.depth, \
+                     b.xy, b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered)
   switch (D) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;
@@ -479,22 +601,16 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 #undef LAUNCH
 }
 
-void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* means3D, const float* shs,
-                               const float* colors_precomp, const float* opacities, const float* scales,
-                               const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, const int32_t* radii, const float* acc,
-                               float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
-                               float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
-                               hipStream_t s) {
-  (void)colors_precomp;
+                               const U3DGradSink& sink, hipStream_t s) {
   const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
   dim3 grid((d.P + U3D_BLOCK - 1) / U3D_BLOCK, d.n_items), block(U3D_BLOCK);
-  const int D = shs ? d.sh_degree : 0;
+  const int D = src.shs ? d.sh_degree : 0;
 #define LAUNCH(DEG)                                                                                                    \
   hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, d.P, d.views_per_item, d.sh_coeffs, d.image_height, \
-                     d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, NG, means3D, shs, opacities, scales, \
-                     rotations, cov3D_precomp, viewmatrix, projmatrix, campos, radii, b.clamped, acc, dL_dmeans3D,     \
-                     dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D)
+                     d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, NG, src, viewmatrix, projmatrix,  \
+                     campos, radii, b.clamped, acc, sink)
   switch (D) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;
@@ -502,6 +618,16 @@ void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, co
     default: LAUNCH(3); break;
   }
 #undef LAUNCH
+}
+
+void u3d_launch_quat_norms(int n_items, int P, const float* rots, int s_rots, float* qnorm, hipStream_t s) {
+  hipLaunchKernelGGL(quat_norms_kernel, dim3(n_items), dim3(U3D_BLOCK), 0, s, P, rots, s_rots, qnorm);
+}
+
+void u3d_launch_quat_fixup(int n_items, int P, const float* rots, int s_rots, const float* qnorm, const float* qdot,
+                           float* d_rots, hipStream_t s) {
+  hipLaunchKernelGGL(quat_fixup_kernel, dim3((P + U3D_BLOCK - 1) / U3D_BLOCK, n_items), dim3(U3D_BLOCK), 0, s, P, rots,
+                     s_rots, qnorm, qdot, d_rots);
 }
 
 void u3d_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s) {

@@ -12,6 +12,8 @@
 // Backward (R5/R6) re-stages the same batches back to front, recovers T by division, and reduces each
 // Gaussian's 10 screen-space gradient components across the wave with DPP row operations before ONE
 // LDS add per wave and ONE global atomic per tile (the original: one atomic per pixel per component).
+#include <cstdlib>
+
 #include "u3d_common.h"
 
 namespace {
@@ -25,13 +27,26 @@ __device__ __forceinline__ bool rect_hits(const uint2 r, int tx, int ty) {
   return tx >= x0 && tx < x1 && ty >= y0 && ty < y1;
 }
 
+// per-pixel loss term and its weight (utils/loss_utils.py:20-45).  torch.isclose(gt, bg, atol=1e-6) uses rtol=1e-5.
+__device__ __forceinline__ float focal_weight(const U3DLoss& L, const float* __restrict__ bg, float g0, float g1, float g2) {
+  if (L.kind != 2) return 1.f;
+  const bool is_bg = fabsf(g0 - bg[0]) <= 1e-6f + 1e-5f * fabsf(bg[0]) && fabsf(g1 - bg[1]) <= 1e-6f + 1e-5f * fabsf(bg[1]) &&
+                     fabsf(g2 - bg[2]) <= 1e-6f + 1e-5f * fabsf(bg[2]);
+  return is_bg ? L.w_bg : L.w_non;
+}
+__device__ __forceinline__ float loss_pixel(const U3DLoss& L, const float* __restrict__ bg, float g0, float g1, float g2,
+                                            float d0, float d1, float d2) {
+  if (L.kind == 3) return fabsf(d0) + fabsf(d1) + fabsf(d2);
+  return focal_weight(L, bg, g0, g1, g2) * (d0 * d0 + d1 * d1 + d2 * d2);
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(U3D_BLOCK) void render_fwd_kernel(
     int P, int H, int W, int tiles_x, int T, uint32_t nblocks, const uint32_t* __restrict__ sorted_id,
     const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis, const float2* __restrict__ xy,
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib) {
+    uint32_t* __restrict__ n_contrib, U3DLoss loss) {
   __shared__ float4 sA[U3D_BLOCK];    // x, y, -0.5*log2e*a, -log2e*b
   __shared__ float2 sB[U3D_BLOCK];    // -0.5*log2e*c, opacity
   __shared__ float4 sC[U3D_BLOCK];    // r, g, b, 1/depth
@@ -114,6 +129,27 @@ __global__ __launch_bounds__(U3D_BLOCK) void render_fwd_kernel(
     oc[2 * npix] = fmaf(Tr, bg[2], C2);
     if (out_invdepth) out_invdepth[(size_t)view * npix + pid] = Dv;
   }
+  if (loss.kind != 0) {
+    // fused render loss (utils/loss_utils.py:17-45): this tile's partial sum, reduced in a fixed order
+    float e = 0.f;
+    if (inside) {
+      const size_t npix = (size_t)H * W;
+      const size_t pid = (size_t)py * W + px;
+      const float* gp = loss.gt + (size_t)view * 3 * npix + pid;
+      const float g0 = gp[0], g1 = gp[npix], g2 = gp[2 * npix];
+      const float d0 = fmaf(Tr, bg[0], C0) - g0, d1 = fmaf(Tr, bg[1], C1) - g1, d2 = fmaf(Tr, bg[2], C2) - g2;
+      e = loss_pixel(loss, bg, g0, g1, g2, d0, d1, d2);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+    __syncthreads();  // sCnt is free again
+    if (lane == 0) reinterpret_cast<float*>(sCnt)[wave] = e;
+    __syncthreads();
+    if (tid == 0) {
+      const float* sp = reinterpret_cast<const float*>(sCnt);
+      loss.partial[lid] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+    }
+  }
 }
 
 // ---- wave64 sum via DPP: result valid in lane 63 ---------------------------------------------
@@ -137,7 +173,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void render_bwd_kernel(
     const uint2* __restrict__ sorted_rect, const float2* __restrict__ xy, const float4* __restrict__ conic_op,
     const float4* __restrict__ rgbd, const float* __restrict__ bg, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dinvdepth, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    float* __restrict__ acc) {
+    float* __restrict__ acc, const float* __restrict__ out_color, U3DLoss loss) {
   __shared__ float4 sA[U3D_BLOCK];   // x, y, a, b
   __shared__ float4 sB[U3D_BLOCK];   // c, opacity, 1/depth, -
   __shared__ float4 sC[U3D_BLOCK];   // r, g, b, -
@@ -162,9 +198,26 @@ __global__ __launch_bounds__(U3D_BLOCK) void render_bwd_kernel(
   const uint32_t last = inside ? n_contrib[(size_t)view * npix + pid] : 0u;
   float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, dinv = 0.f;
   if (inside) {
-    const float* dc = dL_dcolor + (size_t)view * 3 * npix + pid;
-    dp0 = dc[0]; dp1 = dc[npix]; dp2 = dc[2 * npix];
-    if (dL_dinvdepth) dinv = dL_dinvdepth[(size_t)view * npix + pid];
+    if (loss.kind != 0) {
+      // dL/dcolor seed of the fused loss: 2 w (x - gt) / N * dL/dloss   (l1: sign(x - gt) / N)
+      const float* xp = out_color + (size_t)view * 3 * npix + pid;
+      const float* gp = loss.gt + (size_t)view * 3 * npix + pid;
+      const float g0 = gp[0], g1 = gp[npix], g2 = gp[2 * npix];
+      const float d0 = xp[0] - g0, d1 = xp[npix] - g1, d2 = xp[2 * npix] - g2;
+      const float sc = loss.dloss[0] * loss.inv_count;
+      if (loss.kind == 3) {
+        dp0 = sc * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
+        dp1 = sc * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+        dp2 = sc * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
+      } else {
+        const float w2 = 2.f * sc * focal_weight(loss, bg, g0, g1, g2);
+        dp0 = w2 * d0; dp1 = w2 * d1; dp2 = w2 * d2;
+      }
+    } else {
+      const float* dc = dL_dcolor + (size_t)view * 3 * npix + pid;
+      dp0 = dc[0]; dp1 = dc[npix]; dp2 = dc[2 * npix];
+      if (dL_dinvdepth) dinv = dL_dinvdepth[(size_t)view * npix + pid];
+    }
   }
   const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
@@ -275,27 +328,228 @@ __global__ __launch_bounds__(U3D_BLOCK) void render_bwd_kernel(
   }
 }
 
+// ---- backward, wave-per-tile form --------------------------------------------------------------
+// One WAVE owns one 16x16 tile (4 pixels per lane: column lane&15, rows (lane>>4) + 4k), a workgroup is
+// four independent tiles: no workgroup barrier anywhere, LDS regions are wave-private.  Per Gaussian the
+// gradients are accumulated as MOMENTS of q = dL/dG * G over the pixel offsets,
+//     m0 = sum q, mx = sum q dx, my = sum q dy, mxx = sum q dx^2, mxy = sum q dx dy, myy = sum q dy^2,
+// first across the lane's 4 pixels (plain FMAs), then ONE DPP tree per component per tile (the 4-wave
+// form needs four trees plus LDS atomics).  Lane 63 turns the moments into the 10 accumulator values:
+//     dL/dmean2D = -(W/2, H/2) * (a mx + b my, c my + b mx),  dL/dconic = -1/2 (mxx, mxy, myy),
+//     dL/dopacity = m0 / opacity.
+template <bool HAS_INVD>
+__global__ __launch_bounds__(U3D_BLOCK) void render_bwd_wave_kernel(
+    int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t nblocks, size_t NG,
+    const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const float2* __restrict__ xy,
+    const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
+    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_dinvdepth, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, float* __restrict__ acc, const float* __restrict__ out_color, U3DLoss loss) {
+  __shared__ float4 sA[4][U3D_WAVE];   // x, y, a, b
+  __shared__ float4 sB[4][U3D_WAVE];   // c, opacity, 1/depth, pos (bits)
+  __shared__ float4 sC[4][U3D_WAVE];   // r, g, b, id (bits)
+  __shared__ float sAcc[4][U3D_NACC][U3D_WAVE];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t lid = u3d_xcd_remap(blockIdx.x, nblocks) * 4u + (uint32_t)wave;
+  if (lid >= ntiles_total) return;   // whole wave leaves; no barriers below
+  const int view = lid / T, tile = lid - view * T;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int px = tx * U3D_TILE + (lane & 15);
+  const int py0 = ty * U3D_TILE + (lane >> 4);
+  const float pxf = (float)px;
+  const size_t vbase = (size_t)view * P;
+  const size_t npix = (size_t)H * W;
+  const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+
+  float T_final[4], Tr[4], dp0[4], dp1[4], dp2[4], dinv[4], bg_dot[4], pyf[4];
+  float ar0[4], ar1[4], ar2[4], lc0[4], lc1[4], lc2[4], last_alpha[4], ainv[4], linv[4];
+  uint32_t last[4];
+  uint32_t wmax = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int py = py0 + 4 * k;
+    pyf[k] = (float)py;
+    const bool inside = px < W && py < H;
+    const size_t pid = (size_t)py * W + px;
+    T_final[k] = inside ? final_T[(size_t)view * npix + pid] : 0.f;
+    last[k] = inside ? n_contrib[(size_t)view * npix + pid] : 0u;
+    dp0[k] = dp1[k] = dp2[k] = dinv[k] = 0.f;
+    if (inside) {
+      if (loss.kind != 0) {
+        const float* xp = out_color + (size_t)view * 3 * npix + pid;
+        const float* gp = loss.gt + (size_t)view * 3 * npix + pid;
+        const float g0 = gp[0], g1 = gp[npix], g2 = gp[2 * npix];
+        const float d0 = xp[0] - g0, d1 = xp[npix] - g1, d2 = xp[2 * npix] - g2;
+        const float sc = loss.dloss[0] * loss.inv_count;
+        if (loss.kind == 3) {
+          dp0[k] = sc * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
+          dp1[k] = sc * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+          dp2[k] = sc * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
+        } else {
+          const float w2 = 2.f * sc * focal_weight(loss, bg, g0, g1, g2);
+          dp0[k] = w2 * d0; dp1[k] = w2 * d1; dp2[k] = w2 * d2;
+        }
+      } else {
+        const float* dc = dL_dcolor + (size_t)view * 3 * npix + pid;
+        dp0[k] = dc[0]; dp1[k] = dc[npix]; dp2[k] = dc[2 * npix];
+        if (HAS_INVD) dinv[k] = dL_dinvdepth[(size_t)view * npix + pid];
+      }
+    }
+    bg_dot[k] = bg[0] * dp0[k] + bg[1] * dp1[k] + bg[2] * dp2[k];
+    Tr[k] = T_final[k];
+    ar0[k] = ar1[k] = ar2[k] = lc0[k] = lc1[k] = lc2[k] = last_alpha[k] = ainv[k] = linv[k] = 0.f;
+    wmax = max(wmax, last[k]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o));
+
+  const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
+  for (int b = nb - 1; b >= 0; --b) {
+    const uint32_t s = (uint32_t)b * U3D_WAVE + (uint32_t)lane;
+    bool hit = false;
+    if (s < wmax) hit = rect_hits(sorted_rect[vbase + s], tx, ty);
+    const unsigned long long bal = __ballot(hit);
+    const int total = __popcll(bal);
+    if (total == 0) continue;
+    if (hit) {
+      const uint32_t o = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      const uint32_t id = sorted_id[vbase + s];
+      const size_t g = vbase + id;
+      const float2 m = xy[g];
+      const float4 co = conic_op[g];
+      const float4 cd = rgbd[g];
+      sA[wave][o] = make_float4(m.x, m.y, co.x, co.y);
+      sB[wave][o] = make_float4(co.z, co.w, 1.0f / cd.w, __uint_as_float(s + 1u));
+      sC[wave][o] = make_float4(cd.x, cd.y, cd.z, __uint_as_float(id));
+    }
+#pragma unroll
+    for (int k = 0; k < U3D_NACC; ++k) sAcc[wave][k][lane] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int j = total - 1; j >= 0; --j) {
+      const float4 A = sA[wave][j];
+      const float4 B = sB[wave][j];
+      const float4 Cc = sC[wave][j];
+      const uint32_t pos = __float_as_uint(B.w);
+      const float dx = A.x - pxf;
+      float m0 = 0.f, mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dy = A.y - pyf[k];
+        const float pw = fmaf(-0.5f * LOG2E * A.z * dx, dx, fmaf(-0.5f * LOG2E * B.x * dy, dy, -LOG2E * A.w * dx * dy));
+        const float G = __builtin_amdgcn_exp2f(pw);
+        const float alpha = fminf(0.99f, B.y * G);
+        const bool ok = pos <= last[k] && pw <= 0.f && alpha >= ALPHA_MIN;
+        if (ok) {
+          any = true;
+          const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
+          Tr[k] = Tr[k] * rc;
+          const float w = alpha * Tr[k];
+          const float la = last_alpha[k];
+          ar0[k] = la * lc0[k] + (1.f - la) * ar0[k]; lc0[k] = Cc.x;
+          ar1[k] = la * lc1[k] + (1.f - la) * ar1[k]; lc1[k] = Cc.y;
+          ar2[k] = la * lc2[k] + (1.f - la) * ar2[k]; lc2[k] = Cc.z;
+          float dL_dalpha = (Cc.x - ar0[k]) * dp0[k] + (Cc.y - ar1[k]) * dp1[k] + (Cc.z - ar2[k]) * dp2[k];
+          g_r = fmaf(w, dp0[k], g_r); g_g = fmaf(w, dp1[k], g_g); g_b = fmaf(w, dp2[k], g_b);
+          if (HAS_INVD) {
+            ainv[k] = la * linv[k] + (1.f - la) * ainv[k]; linv[k] = B.z;
+            dL_dalpha += (B.z - ainv[k]) * dinv[k];
+            g_d = fmaf(w, dinv[k], g_d);
+          }
+          dL_dalpha *= Tr[k];
+          last_alpha[k] = alpha;
+          dL_dalpha += (-T_final[k] * rc) * bg_dot[k];
+          const float q = B.y * dL_dalpha * G;    // dL/dG * G
+          const float qdx = q * dx, qdy = q * dy;
+          m0 += q; mx += qdx; my += qdy;
+          mxx = fmaf(qdx, dx, mxx); mxy = fmaf(qdx, dy, mxy); myy = fmaf(qdy, dy, myy);
+        }
+      }
+      if (__ballot(any) == 0ull) continue;
+      m0 = wave_sum_to_lane63(m0); mx = wave_sum_to_lane63(mx); my = wave_sum_to_lane63(my);
+      mxx = wave_sum_to_lane63(mxx); mxy = wave_sum_to_lane63(mxy); myy = wave_sum_to_lane63(myy);
+      g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+      if (HAS_INVD) g_d = wave_sum_to_lane63(g_d);
+      if (lane == 63) {
+        sAcc[wave][0][j] = -ddelx_dx * (A.z * mx + A.w * my);
+        sAcc[wave][1][j] = -ddely_dy * (B.x * my + A.w * mx);
+        sAcc[wave][2][j] = -0.5f * mxx;
+        sAcc[wave][3][j] = -0.5f * mxy;
+        sAcc[wave][4][j] = -0.5f * myy;
+        sAcc[wave][5][j] = m0 / B.y;
+        sAcc[wave][6][j] = g_r; sAcc[wave][7][j] = g_g; sAcc[wave][8][j] = g_b;
+        if (HAS_INVD) sAcc[wave][9][j] = g_d;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < total) {
+      const size_t g = vbase + __float_as_uint(sC[wave][lane].w);
+#pragma unroll
+      for (int k = 0; k < (HAS_INVD ? U3D_NACC : U3D_NACC - 1); ++k) {
+        const float v = sAcc[wave][k][lane];
+        if (v != 0.f) unsafeAtomicAdd(&acc[(size_t)k * NG + g], v);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(U3D_BLOCK) void loss_reduce_kernel(int n, const float* __restrict__ partial, float inv_count,
+                                                                float* __restrict__ loss_out) {
+  __shared__ float sm[U3D_BLOCK];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += U3D_BLOCK) a += partial[i];
+  sm[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = U3D_BLOCK / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[0] = sm[0] * inv_count;
+}
+
 }  // namespace
 
+void u3d_launch_loss_reduce(int n, const float* partial, float inv_count, float* loss_out, hipStream_t s) {
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(U3D_BLOCK), 0, s, n, partial, inv_count, loss_out);
+}
+
 void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,
-                           float* out_invdepth, hipStream_t s) {
+                           float* out_invdepth, const U3DLoss& loss, hipStream_t s) {
   const int tiles_x = (d.image_width + U3D_TILE - 1) / U3D_TILE, tiles_y = (d.image_height + U3D_TILE - 1) / U3D_TILE;
   const int T = tiles_x * tiles_y;
   const uint32_t nblocks = (uint32_t)(d.n_items * d.views_per_item * T);
   if (nblocks == 0) return;
   hipLaunchKernelGGL(render_fwd_kernel, dim3(nblocks), dim3(U3D_BLOCK), 0, s, d.P, d.image_height, d.image_width,
                      tiles_x, T, nblocks, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
-                     out_invdepth, b.final_T, b.n_contrib);
+                     out_invdepth, b.final_T, b.n_contrib, loss);
 }
 
 void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, const float* dL_dcolor,
-                           const float* dL_dinvdepth, float* acc, hipStream_t s) {
+                           const float* dL_dinvdepth, const float* out_color, const U3DLoss& loss, float* acc,
+                           hipStream_t s) {
   const int tiles_x = (d.image_width + U3D_TILE - 1) / U3D_TILE, tiles_y = (d.image_height + U3D_TILE - 1) / U3D_TILE;
   const int T = tiles_x * tiles_y;
   const uint32_t nblocks = (uint32_t)(d.n_items * d.views_per_item * T);
   const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
   if (nblocks == 0 || NG == 0) return;
+  static const bool use_v1 = getenv("U3D_BWD_V1") != nullptr;   // A/B switch for measurements
+  if (!use_v1) {
+    const uint32_t nwg = (nblocks + 3u) / 4u;
+    if (dL_dinvdepth && loss.kind == 0)
+      hipLaunchKernelGGL(render_bwd_wave_kernel<true>, dim3(nwg), dim3(U3D_BLOCK), 0, s, d.P, d.image_height, d.image_width,
+                         tiles_x, T, nblocks, nwg, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg, dL_dcolor,
+                         dL_dinvdepth, b.final_T, b.n_contrib, acc, out_color, loss);
+    else
+      hipLaunchKernelGGL(render_bwd_wave_kernel<false>, dim3(nwg), dim3(U3D_BLOCK), 0, s, d.P, d.image_height, d.image_width,
+                         tiles_x, T, nblocks, nwg, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg, dL_dcolor,
+                         dL_dinvdepth, b.final_T, b.n_contrib, acc, out_color, loss);
+    return;
+  }
   hipLaunchKernelGGL(render_bwd_kernel, dim3(nblocks), dim3(U3D_BLOCK), 0, s, d.P, d.image_height, d.image_width,
                      tiles_x, T, nblocks, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg, dL_dcolor,
-                     dL_dinvdepth, b.final_T, b.n_contrib, acc);
+                     dL_dinvdepth, b.final_T, b.n_contrib, acc, out_color, loss);
 }

@@ -179,5 +179,6 @@ class GaussianHead(nn.Module):
         super().__init__()
         self.final = nn.Sequential(nn.Linear(in_dim, hidden), nn.ReLU(), nn.Linear(hidden, out_dim))
 
-    def forward(self, feats: torch.Tensor) -> torch.Tensor:
-        return self.final(feats).permute(0, 2, 1)
+    def forward(self, feats: torch.Tensor, point_major: bool = False) -> torch.Tensor:
+        out = self.final(feats)                      # (B, N, 23) contiguous
+        return out if point_major else out.permute(0, 2, 1)

@@ -1,0 +1,86 @@
+"""Fused render-loss step (SURVEY.md N2 + N3): from the Gaussian head's Linear output to the scalar loss in one
+launch sequence of the HIP library (`u3d_render_loss_forward/_backward`).
+
+Replaces, per training step: the activation/reshape chain of model/gaussian_predictor.py:279-328, the SH concat and
+operator call of gaussian_renderer/__init__.py:78-97, the per-object/per-view loop and torch.stack of
+train_network.py:418-446 and the elementwise loss of utils/loss_utils.py:17-45 -- about 60 PyTorch kernel launches
+and ~1 GB of intermediate traffic per step at BASELINE config C2.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from .rasterizer import _Plan, _f32c, _stream_ptr
+
+
+class _RenderLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, head_out, center, viewmatrix, projmatrix, campos, gt, bg, H, W, tanfov, mode, offset_scale, sh_degree,
+                loss_kind, non_bg_rate, bg_rate, scale_modifier, flags):
+        lib = _lib.load()
+        dev = head_out.device
+        if dev.type != "cuda":
+            raise RuntimeError("the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback")
+        B, P, C = head_out.shape
+        NV = viewmatrix.shape[0]
+        V = NV // B
+        K = (sh_degree + 1) ** 2
+        if C != 11 + 3 * K:
+            raise ValueError(f"head output has {C} channels, expected {11 + 3 * K} for SH degree {sh_degree}")
+        plan = _Plan(B, V, P, H, W, tanfov, tanfov, scale_modifier, sh_degree, K, flags)
+        hd = _lib.HeadDesc(mode, C, offset_scale)
+        ld = _lib.LossDesc(_lib.LOSS_KINDS[loss_kind], non_bg_rate, bg_rate)
+        color = torch.empty((NV, 3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.zeros((NV, P), dtype=torch.int32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+        geom, binning, image, fused = u8(plan.sizes.geom_bytes), u8(plan.sizes.binning_bytes), u8(plan.sizes.image_bytes), \
+            u8(plan.sizes.fused_bytes)
+        p = _lib.ptr
+        rc = lib.u3d_render_loss_forward(ctypes.byref(plan.desc), ctypes.byref(hd), ctypes.byref(ld), p(bg), p(head_out), p(center),
+                                         p(viewmatrix), p(projmatrix), p(campos), p(gt), p(color), p(radii), p(loss), p(geom),
+                                         p(binning), p(image), p(fused), _stream_ptr())
+        _lib.check(rc, "u3d_render_loss_forward")
+        ctx.plan, ctx.hd, ctx.ld = plan, hd, ld
+        ctx.save_for_backward(head_out, center, viewmatrix, projmatrix, campos, gt, bg, color, radii, geom, binning, image, fused)
+        ctx.mark_non_differentiable(color, radii)
+        return loss, color, radii
+
+    @staticmethod
+    def backward(ctx, grad_loss, _gc, _gr):
+        lib = _lib.load()
+        head_out, center, viewmatrix, projmatrix, campos, gt, bg, color, radii, geom, binning, image, fused = ctx.saved_tensors
+        dev = head_out.device
+        d_head = torch.empty_like(head_out)
+        scratch = torch.empty(ctx.plan.sizes.backward_bytes, dtype=torch.uint8, device=dev)
+        dloss = _f32c(grad_loss, dev).reshape(1)
+        p = _lib.ptr
+        rc = lib.u3d_render_loss_backward(ctypes.byref(ctx.plan.desc), ctypes.byref(ctx.hd), ctypes.byref(ctx.ld), p(bg), p(head_out),
+                                          p(center), p(viewmatrix), p(projmatrix), p(campos), p(gt), p(radii), p(color), p(dloss),
+                                          p(geom), p(binning), p(image), p(fused), p(scratch), p(d_head), _stream_ptr())
+        _lib.check(rc, "u3d_render_loss_backward")
+        return (d_head,) + (None,) * 17
+
+
+def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: torch.Tensor, full_proj: torch.Tensor,
+                      camera_center: torch.Tensor, gt: torch.Tensor, bg: torch.Tensor, fov_deg: float, H: int, W: int,
+                      level: str = "object", offset_scale: float = 1.0, max_sh_degree: int = 1, loss_kind: str = "focal_l2",
+                      non_bg_color_loss_rate: float = 4.0, bg_color_loss_rate: float = 1.0, input_images: int = 0,
+                      scaling_modifier: float = 1.0, antialiasing: bool = True, debug: bool = False):
+    """head_out (B,P,C) point-major raw head output (C = 23 at SH degree 1), center (B,P,3), cameras (B,Vtot,...),
+    gt (B,Vtot,3,H,W).  Returns (loss scalar, rendered (B*V',3,H,W) detached, radii (B*V',P))."""
+    dev = head_out.device
+    B = head_out.shape[0]
+    wv, fp, cc = world_view[:, input_images:], full_proj[:, input_images:], camera_center[:, input_images:]
+    NV = B * wv.shape[1]
+    t = math.tan(fov_deg * math.pi / 360)
+    flags = (_lib.FLAG_ANTIALIASING if antialiasing else 0) | (_lib.FLAG_DEBUG if debug else 0)
+    f = lambda x: _f32c(x, dev)
+    return _RenderLossFn.apply(f(head_out), f(center), f(wv).reshape(NV, 16), f(fp).reshape(NV, 16), f(cc).reshape(NV, 3),
+                               f(gt[:, input_images:]).reshape(NV, 3, H, W), f(bg).reshape(3), int(H), int(W), float(t),
+                               1 if level == "object" else 2, float(offset_scale), int(max_sh_degree), loss_kind,
+                               float(non_bg_color_loss_rate), float(bg_color_loss_rate), float(scaling_modifier), flags)

@@ -36,12 +36,20 @@ def render_loss_forward(raw: torch.Tensor, batch: SyntheticBatch, H: int, W: int
 
 def train_step(model: torch.nn.Module, feats: torch.Tensor, batch: SyntheticBatch, optimizer: torch.optim.Optimizer, H: int,
                W: int, input_images: int = 0, loss_kind: str = "focal_l2", render_fn: Optional[Callable] = None,
-               clip_grad: Optional[float] = 1.0) -> torch.Tensor:
+               clip_grad: Optional[float] = 1.0, fused: bool = False) -> torch.Tensor:
     """zero_grad -> head -> render-loss -> backward (DDP all-reduce inside) -> clip -> optimizer step
-    (train_network.py:329-352 without the per-parameter NaN scan's host syncs)."""
+    (train_network.py:329-352 without the per-parameter NaN scan's host syncs).
+    fused=True: activations + batched render + loss run inside the HIP library (fused.render_loss_fused)."""
     optimizer.zero_grad(set_to_none=True)
-    raw = model(feats)
-    loss, _ = render_loss_forward(raw, batch, H, W, input_images, loss_kind, render_fn)
+    if fused:
+        from .fused import render_loss_fused
+        head_out = model(feats, point_major=True)
+        loss, _, _ = render_loss_fused(head_out, batch.center, batch.world_view, batch.full_proj, batch.camera_center, batch.gt,
+                                       batch.bg, batch.fov_deg, H, W, level=batch.level, offset_scale=batch.offset_scale,
+                                       loss_kind=loss_kind, input_images=input_images)
+    else:
+        raw = model(feats)
+        loss, _ = render_loss_forward(raw, batch, H, W, input_images, loss_kind, render_fn)
     loss.backward()
     if clip_grad is not None:
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip_grad)
