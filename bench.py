@@ -106,7 +106,7 @@ def main():
         model.final[2].weight.div_(raw0.std())
         model.final[2].bias.zero_()
     model = dp.create_ddp_model(model, sync_bn=False)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, eps=1e-15)  # train_network.py:156-158 (group lr 1e-4)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, eps=1e-15, fused=True)  # train_network.py:156-158 (group lr 1e-4)
     loss_kind = "focal_l2" if level == "object" else "l2"
 
     def one_step():

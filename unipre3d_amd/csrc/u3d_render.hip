@@ -497,14 +497,19 @@ __global__ __launch_bounds__(U3D_BLOCK) void render_bwd_wave_kernel(
   }
 }
 
-__global__ __launch_bounds__(U3D_BLOCK) void loss_reduce_kernel(int n, const float* __restrict__ partial, float inv_count,
-                                                                float* __restrict__ loss_out) {
-  __shared__ float sm[U3D_BLOCK];
-  float a = 0.f;
-  for (int i = threadIdx.x; i < n; i += U3D_BLOCK) a += partial[i];
-  sm[threadIdx.x] = a;
+// Fixed-order sum of the per-tile partials (deterministic): 1024 threads, 4 independent accumulators each.
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(int n, const float* __restrict__ partial, float inv_count,
+                                                           float* __restrict__ loss_out) {
+  __shared__ float sm[1024];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int i = threadIdx.x;
+  for (; i + 3072 < n; i += 4096) {
+    a0 += partial[i]; a1 += partial[i + 1024]; a2 += partial[i + 2048]; a3 += partial[i + 3072];
+  }
+  for (; i < n; i += 1024) a0 += partial[i];
+  sm[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  for (int o = U3D_BLOCK / 2; o > 0; o >>= 1) {
+  for (int o = 512; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
     __syncthreads();
   }
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void loss_reduce_kernel(int n, const flo
 }  // namespace
 
 void u3d_launch_loss_reduce(int n, const float* partial, float inv_count, float* loss_out, hipStream_t s) {
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(U3D_BLOCK), 0, s, n, partial, inv_count, loss_out);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, n, partial, inv_count, loss_out);
 }
 
 void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,

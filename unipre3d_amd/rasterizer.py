@@ -52,12 +52,23 @@ def _none_if_empty(t):
 
 
 class _Plan:
-    """Descriptor + scratch sizes for one call shape."""
+    """Descriptor + scratch sizes for one call shape (cached: the per-view drop-in route calls this B*V times a step)."""
+    _cache = {}
 
-    def __init__(self, n_items, vpi, P, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, M, flags):
-        self.desc = _lib.RasterDesc(n_items, vpi, P, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, M, flags)
+    def __new__(cls, *key):
+        hit = cls._cache.get(key)
+        if hit is not None:
+            return hit
+        self = super().__new__(cls)
+        self.desc = _lib.RasterDesc(*key)
         self.sizes = _lib.ScratchSizes()
         _lib.check(_lib.load().u3d_scratch_query(ctypes.byref(self.desc), ctypes.byref(self.sizes)), "u3d_scratch_query")
+        if len(cls._cache) < 256:
+            cls._cache[key] = self
+        return self
+
+    def __init__(self, n_items, vpi, P, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, M, flags):
+        pass
 
 
 def _stream_ptr():
