@@ -39,6 +39,18 @@ def algorithmic_bytes(kind: str, P: int, R: float, T: int, HW: int) -> float:
     }[kind]
 
 
+def pmc_traffic(kernel: str, config: str, fused: bool):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01/pmc_traffic_C2.json: separate FETCH_SIZE /
+    WRITE_SIZE runs of this very command, FETCH_SIZE doubled per the gfx950 calibration).  None when the run does not
+    match the profiled workload."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_C2.json")
+    if config != "C2" or not fused or not os.path.exists(path):
+        return None
+    per = json.load(open(path))["per_launch"]
+    key = {"render_fwd": "render_fwd_kernel", "render_bwd": "render_bwd_wave_kernel"}.get(kernel)
+    return per[key]["hbm_bytes_corrected"] if key in per else None
+
+
 def cpu_baseline(batch, H, W, min_seconds=10.0, max_views=8):
     """The CPU restatement (oracle/, kind 'port') timed on a bounded sample of the SAME workload:
     forward + focal-L2 + backward for the first `max_views` views, repeated until >= min_seconds."""
@@ -173,7 +185,9 @@ def main():
         }
         if dom:
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None}
+                               "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS,
+                               "traffic": pmc_traffic(dom, a.config, not a.unfused and not a.compact),
+                               "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_GB_per_launch"] * 1e9}
             out["roofline_forward_rasterizer"] = {"achieved": fwd_bytes / 1e9 / (fwd_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                   "frac": fwd_bytes / 1e9 / (fwd_ms / 1e3) / HBM_PEAK_GBS,
                                                   "note": "reference-algorithm bytes 168P+76R+8T+24HW per view over the sum of forward kernel times"}

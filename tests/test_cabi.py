@@ -48,7 +48,7 @@ def test_scratch_query_is_host_arithmetic(lib):
     assert lib.u3d_scratch_query(ctypes.byref(d), ctypes.byref(s)) == 0
     NG, NP = 32 * 4 * 128, 32 * 4 * 256 * 256
     assert s.geom_bytes >= NG * (4 + 8 + 16 + 16 + 8 + 4)
-    assert s.image_bytes >= NP * 8 and s.backward_bytes >= NG * 40 and s.binning_bytes >= NG * 12
+    assert s.image_bytes >= NP * 8 and s.backward_bytes >= NG * 80 and s.binning_bytes >= NG * 12
     assert s.num_rendered_offset % 256 == 0 and s.num_rendered_offset < s.geom_bytes
     # radix temporaries only beyond the LDS-sortable size
     d2 = _lib.RasterDesc(1, 8, 200000, 480, 640, 0.55, 0.55, 1.0, 1, 4, 2)

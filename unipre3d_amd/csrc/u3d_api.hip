@@ -210,11 +210,12 @@ int u3d_rasterize_backward(const u3d_raster_desc* desc, const float* bg, const f
   hipStream_t s = (hipStream_t)stream;
   U3DBuffers b{};
   const U3DLayout L = u3d_carve(d, (void*)geom, (void*)binning, (void*)image, &b);
-  float* acc = (float*)backward_scratch;
-  (void)hipMemsetAsync(acc, 0, L.backward_bytes, s);
+  double* acc = (double*)backward_scratch;
+  float* part = (float*)((char*)backward_scratch + L.acc_bytes);
+  (void)hipMemsetAsync(acc, 0, L.acc_bytes, s);
   {
     ProfScope ps(3, s);
-    u3d_launch_render_bwd(d, b, bg, dL_dcolor, dL_dinvdepth, nullptr, U3DLoss{}, acc, s);
+    u3d_launch_render_bwd(d, b, bg, dL_dcolor, dL_dinvdepth, nullptr, U3DLoss{}, acc, part, s);
   }
   {
     ProfScope ps(4, s);
@@ -285,13 +286,14 @@ int u3d_render_loss_backward(const u3d_raster_desc* desc, const u3d_head_desc* h
   const U3DLayout Lay = u3d_carve(d, (void*)geom, (void*)binning, (void*)image, &b);
   U3DFused f{};
   u3d_carve_fused(d, fused, &f);
-  float* acc = (float*)backward_scratch;
-  (void)hipMemsetAsync(acc, 0, Lay.backward_bytes, s);
+  double* acc = (double*)backward_scratch;
+  float* part = (float*)((char*)backward_scratch + Lay.acc_bytes);
+  (void)hipMemsetAsync(acc, 0, Lay.acc_bytes, s);
   (void)hipMemsetAsync(f.qdot, 0, sizeof(float) * 4 * d.n_items, s);
   const U3DLoss L = make_loss(d, *loss, gt, f.partial, dloss);
   {
     ProfScope ps(3, s);
-    u3d_launch_render_bwd(d, b, bg, nullptr, nullptr, out_color, L, acc, s);
+    u3d_launch_render_bwd(d, b, bg, nullptr, nullptr, out_color, L, acc, part, s);
   }
   const int C = head->channels;
   U3DGradSink sink{};

@@ -74,7 +74,7 @@ struct U3DLoss {
 };
 
 struct U3DLayout {
-  size_t geom_bytes, binning_bytes, image_bytes, backward_bytes, num_rendered_offset, fused_bytes;
+  size_t geom_bytes, binning_bytes, image_bytes, backward_bytes, acc_bytes, num_rendered_offset, fused_bytes;
 };
 
 // fused scratch: [qnorm n_items*4][qdot n_items*4][loss partial NV*T]
@@ -138,7 +138,13 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
   CARVE(im, n_contrib, uint32_t, NP);
   L.image_bytes = o > 0 ? o : 256;
 #undef CARVE
-  L.backward_bytes = u3d_align(sizeof(float) * U3D_NACC * (NG > 0 ? NG : 1));
+  // f64 accumulators: global_atomic_add_f64 makes the cross-tile sum order-insensitive at fp32 output precision
+  // + per-tile partials of the first 64 sorted positions: [NV*T][U3D_NACC][64] floats (see render_bwd_wave_kernel)
+  L.acc_bytes = u3d_align(sizeof(double) * U3D_NACC * (NG > 0 ? NG : 1));
+  {
+    const size_t Tn = (size_t)((d.image_width + U3D_TILE - 1) / U3D_TILE) * ((d.image_height + U3D_TILE - 1) / U3D_TILE);
+    L.backward_bytes = L.acc_bytes + u3d_align(sizeof(float) * U3D_NACC * U3D_WAVE * (NV * Tn > 0 ? NV * Tn : 1));
+  }
   L.fused_bytes = u3d_carve_fused(d, nullptr, nullptr);
   return L;
 }
@@ -147,7 +153,7 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
 void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, int32_t* radii, hipStream_t s);
 void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
-                               const float* projmatrix, const float* campos, const int32_t* radii, const float* acc,
+                               const float* projmatrix, const float* campos, const int32_t* radii, const double* acc,
                                const U3DGradSink& sink, hipStream_t s);
 void u3d_launch_quat_norms(int n_items, int P, const float* rots, int s_rots, float* qnorm, hipStream_t s);
 void u3d_launch_quat_fixup(int n_items, int P, const float* rots, int s_rots, const float* qnorm, const float* qdot,
@@ -156,8 +162,8 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
 void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,
                            float* out_invdepth, const U3DLoss& loss, hipStream_t s);
 void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, const float* dL_dcolor,
-                           const float* dL_dinvdepth, const float* out_color, const U3DLoss& loss, float* acc,
-                           hipStream_t s);
+                           const float* dL_dinvdepth, const float* out_color, const U3DLoss& loss, double* acc,
+                           float* part, hipStream_t s);
 void u3d_launch_loss_reduce(int n, const float* partial, float inv_count, float* loss_out, hipStream_t s);
 
 #ifdef __HIPCC__

@@ -260,7 +260,7 @@ template <int D>
 __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     int P, int vpi, int M, int H, int W, float tanx, float tany, float mod, int flags, size_t NG, U3DSource src,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
-    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const float* __restrict__ acc,
+    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const double* __restrict__ acc,
     U3DGradSink sink) {
   __shared__ float s_qdot[4][4];
   const int item = blockIdx.y;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     const bool live = radii[g] > 0;
     float a[U3D_NACC];
 #pragma unroll
-    for (int k = 0; k < U3D_NACC; ++k) a[k] = live ? acc[(size_t)k * NG + g] : 0.f;
+    for (int k = 0; k < U3D_NACC; ++k) a[k] = live ? (float)acc[(size_t)k * NG + g] : 0.f;
     if (dL_dmeans2D) {
       dL_dmeans2D[g * 3] = a[0]; dL_dmeans2D[g * 3 + 1] = a[1]; dL_dmeans2D[g * 3 + 2] = 0.f;
     }
@@ -602,7 +602,7 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 }
 
 void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
-                               const float* projmatrix, const float* campos, const int32_t* radii, const float* acc,
+                               const float* projmatrix, const float* campos, const int32_t* radii, const double* acc,
                                const U3DGradSink& sink, hipStream_t s) {
   const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
   dim3 grid((d.P + U3D_BLOCK - 1) / U3D_BLOCK, d.n_items), block(U3D_BLOCK);

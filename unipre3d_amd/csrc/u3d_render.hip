@@ -152,6 +152,122 @@ __global__ __launch_bounds__(U3D_BLOCK) void render_fwd_kernel(
   }
 }
 
+// ---- forward, wave-per-tile form ---------------------------------------------------------------
+// One WAVE renders one 16x16 tile, 4 pixels per lane (column lane&15, rows (lane>>4)+4k): the per-Gaussian LDS
+// broadcast reads, loop control and exponent set-up are shared by 4 pixels (4-way ILP), batches are 64 sorted
+// entries (the reference's splats saturate a pixel after ~17 entries, so one batch usually suffices), LDS regions
+// are wave-private and there is no workgroup barrier.  A workgroup is four independent tiles.
+__global__ __launch_bounds__(U3D_BLOCK) void render_fwd_wave_kernel(
+    int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t nblocks, const uint32_t* __restrict__ sorted_id,
+    const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis, const float2* __restrict__ xy,
+    const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
+    float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib, U3DLoss loss) {
+  __shared__ float4 sA[4][U3D_WAVE];   // x, y, -0.5*log2e*a, -log2e*b
+  __shared__ float4 sB[4][U3D_WAVE];   // -0.5*log2e*c, opacity, 1/depth, pos (bits)
+  __shared__ float4 sC[4][U3D_WAVE];   // r, g, b, -
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t lid = u3d_xcd_remap(blockIdx.x, nblocks) * 4u + (uint32_t)wave;
+  if (lid >= ntiles_total) return;
+  const int view = lid / T, tile = lid - view * T;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int px = tx * U3D_TILE + (lane & 15);
+  const int py0 = ty * U3D_TILE + (lane >> 4);
+  const float pxf = (float)px;
+  const size_t vbase = (size_t)view * P;
+  const uint32_t nv = n_vis[view];
+
+  float Tr[4], C0[4], C1[4], C2[4], Dv[4], pyf[4];
+  uint32_t last[4];
+  bool done[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int py = py0 + 4 * k;
+    pyf[k] = (float)py;
+    Tr[k] = 1.f; C0[k] = C1[k] = C2[k] = Dv[k] = 0.f; last[k] = 0u;
+    done[k] = !(px < W && py < H);
+  }
+  bool all_done = done[0] && done[1] && done[2] && done[3];
+
+  for (uint32_t base = 0; base < nv; base += U3D_WAVE) {
+    if (__ballot(!all_done) == 0ull) break;
+    const uint32_t s = base + (uint32_t)lane;
+    bool hit = false;
+    if (s < nv) hit = rect_hits(sorted_rect[vbase + s], tx, ty);
+    const unsigned long long bal = __ballot(hit);
+    const int total = __popcll(bal);
+    if (total == 0) continue;
+    if (hit) {
+      const uint32_t o = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      const size_t g = vbase + sorted_id[vbase + s];
+      const float2 m = xy[g];
+      const float4 co = conic_op[g];
+      const float4 cd = rgbd[g];
+      sA[wave][o] = make_float4(m.x, m.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
+      sB[wave][o] = make_float4(-0.5f * LOG2E * co.z, co.w, 1.0f / cd.w, __uint_as_float(s + 1u));
+      sC[wave][o] = make_float4(cd.x, cd.y, cd.z, 0.f);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < total; ++j) {
+      const float4 A = sA[wave][j];
+      const float4 B = sB[wave][j];
+      const float4 Cc = sC[wave][j];
+      const float dx = A.x - pxf;
+      const float adx = A.z * dx, bdx = A.w * dx;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dy = A.y - pyf[k];
+        const float pw = fmaf(adx, dx, fmaf(B.x * dy, dy, bdx * dy));
+        const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(pw));
+        const bool ok = !done[k] && pw <= 0.f && alpha >= ALPHA_MIN;
+        const float test_T = Tr[k] * (1.f - alpha);
+        const bool stop = ok && test_T < T_STOP;
+        done[k] = done[k] || stop;
+        if (ok && !stop) {
+          const float w = alpha * Tr[k];
+          C0[k] = fmaf(Cc.x, w, C0[k]);
+          C1[k] = fmaf(Cc.y, w, C1[k]);
+          C2[k] = fmaf(Cc.z, w, C2[k]);
+          Dv[k] = fmaf(B.z, w, Dv[k]);
+          Tr[k] = test_T;
+          last[k] = __float_as_uint(B.w);
+        }
+      }
+      all_done = done[0] && done[1] && done[2] && done[3];
+      if (__ballot(!all_done) == 0ull) break;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  const size_t npix = (size_t)H * W;
+  float e = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int py = py0 + 4 * k;
+    if (px < W && py < H) {
+      const size_t pid = (size_t)py * W + px;
+      final_T[(size_t)view * npix + pid] = Tr[k];
+      n_contrib[(size_t)view * npix + pid] = last[k];
+      const float o0 = fmaf(Tr[k], bg[0], C0[k]), o1 = fmaf(Tr[k], bg[1], C1[k]), o2 = fmaf(Tr[k], bg[2], C2[k]);
+      float* oc = out_color + (size_t)view * 3 * npix + pid;
+      oc[0] = o0; oc[npix] = o1; oc[2 * npix] = o2;
+      if (out_invdepth) out_invdepth[(size_t)view * npix + pid] = Dv[k];
+      if (loss.kind != 0) {
+        const float* gp = loss.gt + (size_t)view * 3 * npix + pid;
+        const float g0 = gp[0], g1 = gp[npix], g2 = gp[2 * npix];
+        e += loss_pixel(loss, bg, g0, g1, g2, o0 - g0, o1 - g1, o2 - g2);
+      }
+    }
+  }
+  if (loss.kind != 0) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+    if (lane == 0) loss.partial[lid] = e;
+  }
+}
+
 // ---- wave64 sum via DPP: result valid in lane 63 ---------------------------------------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -173,7 +289,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void render_bwd_kernel(
     const uint2* __restrict__ sorted_rect, const float2* __restrict__ xy, const float4* __restrict__ conic_op,
     const float4* __restrict__ rgbd, const float* __restrict__ bg, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dinvdepth, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    float* __restrict__ acc, const float* __restrict__ out_color, U3DLoss loss) {
+    double* __restrict__ acc, const float* __restrict__ out_color, U3DLoss loss) {
   __shared__ float4 sA[U3D_BLOCK];   // x, y, a, b
   __shared__ float4 sB[U3D_BLOCK];   // c, opacity, 1/depth, -
   __shared__ float4 sC[U3D_BLOCK];   // r, g, b, -
@@ -322,179 +438,227 @@ __global__ __launch_bounds__(U3D_BLOCK) void render_bwd_kernel(
 #pragma unroll
       for (int k = 0; k < U3D_NACC; ++k) {
         const float v = sAcc[k][tid];
-        if (v != 0.f) unsafeAtomicAdd(&acc[(size_t)k * NG + g], v);
+        if (v != 0.f) unsafeAtomicAdd(&acc[(size_t)k * NG + g], (double)v);
       }
     }
   }
 }
 
 // ---- backward, wave-per-tile form --------------------------------------------------------------
-// One WAVE owns one 16x16 tile (4 pixels per lane: column lane&15, rows (lane>>4) + 4k), a workgroup is
-// four independent tiles: no workgroup barrier anywhere, LDS regions are wave-private.  Per Gaussian the
-// gradients are accumulated as MOMENTS of q = dL/dG * G over the pixel offsets,
+// One WAVE owns one 16x16 tile (4 pixels per lane: column lane&15, rows (lane>>4) + 4k); a workgroup is
+// BWD_WAVES independent tiles: the batch loop has no workgroup barrier, LDS regions are wave-private.  Per
+// Gaussian the gradients are accumulated as MOMENTS of q = dL/dG * G over the pixel offsets,
 //     m0 = sum q, mx = sum q dx, my = sum q dy, mxx = sum q dx^2, mxy = sum q dx dy, myy = sum q dy^2,
-// first across the lane's 4 pixels (plain FMAs), then ONE DPP tree per component per tile (the 4-wave
-// form needs four trees plus LDS atomics).  Lane 63 turns the moments into the 10 accumulator values:
+// first across the lane's 4 pixels (plain FMAs), then ONE DPP tree per component per tile.  Lane 63 turns the
+// moments into the accumulator values:
 //     dL/dmean2D = -(W/2, H/2) * (a mx + b my, c my + b mx),  dL/dconic = -1/2 (mxx, mxy, myy),
 //     dL/dopacity = m0 / opacity.
+// Cross-tile accumulation without atomics in the common case: the first 64 positions of the view's sorted list
+// -- where the reference's large, fairly opaque splats put essentially all contributions (a pixel saturates after
+// ~17 entries) -- are written per tile to a partial buffer part[view][tile][component][position] (plain coalesced
+// stores) and summed over the tiles in a FIXED order, in f64, by bwd_reduce_kernel.  Only sorted positions >= 64
+// (sparse / semi-transparent scenes) fall back to f64 global atomics, whose ordering does not show at fp32 output
+// precision.  The result is therefore run-to-run deterministic, unlike the original's fp32 atomics.
+constexpr int BWD_WAVES = 4;
+
 template <bool HAS_INVD>
-__global__ __launch_bounds__(U3D_BLOCK) void render_bwd_wave_kernel(
+__global__ __launch_bounds__(BWD_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
     int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t nblocks, size_t NG,
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const float2* __restrict__ xy,
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_dinvdepth, const float* __restrict__ final_T,
-    const uint32_t* __restrict__ n_contrib, float* __restrict__ acc, const float* __restrict__ out_color, U3DLoss loss) {
-  __shared__ float4 sA[4][U3D_WAVE];   // x, y, a, b
-  __shared__ float4 sB[4][U3D_WAVE];   // c, opacity, 1/depth, pos (bits)
-  __shared__ float4 sC[4][U3D_WAVE];   // r, g, b, id (bits)
-  __shared__ float sAcc[4][U3D_NACC][U3D_WAVE];
+    const uint32_t* __restrict__ n_contrib, double* __restrict__ acc, float* __restrict__ part,
+    const float* __restrict__ out_color, U3DLoss loss) {
+  constexpr int NK = HAS_INVD ? U3D_NACC : U3D_NACC - 1;
+  __shared__ float4 sA[BWD_WAVES][U3D_WAVE];   // x, y, a, b
+  __shared__ float4 sB[BWD_WAVES][U3D_WAVE];   // c, opacity, 1/depth, pos (bits)
+  __shared__ float4 sC[BWD_WAVES][U3D_WAVE];   // r, g, b, id (bits)
+  __shared__ float sAcc[BWD_WAVES][U3D_NACC][U3D_WAVE];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const uint32_t lid = u3d_xcd_remap(blockIdx.x, nblocks) * 4u + (uint32_t)wave;
-  if (lid >= ntiles_total) return;   // whole wave leaves; no barriers below
-  const int view = lid / T, tile = lid - view * T;
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  const int px = tx * U3D_TILE + (lane & 15);
-  const int py0 = ty * U3D_TILE + (lane >> 4);
-  const float pxf = (float)px;
-  const size_t vbase = (size_t)view * P;
-  const size_t npix = (size_t)H * W;
-  const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+  const uint32_t lid = u3d_xcd_remap(blockIdx.x, nblocks) * (uint32_t)BWD_WAVES + (uint32_t)wave;
+  if (lid >= ntiles_total) return;   // whole wave leaves; there is no workgroup barrier below
+  const int view = (int)(lid / T);
+#pragma unroll
+  for (int k = 0; k < NK; ++k) sAcc[wave][k][lane] = 0.f;
 
-  float T_final[4], Tr[4], dp0[4], dp1[4], dp2[4], dinv[4], bg_dot[4], pyf[4];
-  float ar0[4], ar1[4], ar2[4], lc0[4], lc1[4], lc2[4], last_alpha[4], ainv[4], linv[4];
-  uint32_t last[4];
-  uint32_t wmax = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int py = py0 + 4 * k;
-    pyf[k] = (float)py;
-    const bool inside = px < W && py < H;
-    const size_t pid = (size_t)py * W + px;
-    T_final[k] = inside ? final_T[(size_t)view * npix + pid] : 0.f;
-    last[k] = inside ? n_contrib[(size_t)view * npix + pid] : 0u;
-    dp0[k] = dp1[k] = dp2[k] = dinv[k] = 0.f;
-    if (inside) {
-      if (loss.kind != 0) {
-        const float* xp = out_color + (size_t)view * 3 * npix + pid;
-        const float* gp = loss.gt + (size_t)view * 3 * npix + pid;
-        const float g0 = gp[0], g1 = gp[npix], g2 = gp[2 * npix];
-        const float d0 = xp[0] - g0, d1 = xp[npix] - g1, d2 = xp[2 * npix] - g2;
-        const float sc = loss.dloss[0] * loss.inv_count;
-        if (loss.kind == 3) {
-          dp0[k] = sc * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
-          dp1[k] = sc * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
-          dp2[k] = sc * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
-        } else {
-          const float w2 = 2.f * sc * focal_weight(loss, bg, g0, g1, g2);
-          dp0[k] = w2 * d0; dp1[k] = w2 * d1; dp2[k] = w2 * d2;
-        }
-      } else {
-        const float* dc = dL_dcolor + (size_t)view * 3 * npix + pid;
-        dp0[k] = dc[0]; dp1[k] = dc[npix]; dp2[k] = dc[2 * npix];
-        if (HAS_INVD) dinv[k] = dL_dinvdepth[(size_t)view * npix + pid];
-      }
-    }
-    bg_dot[k] = bg[0] * dp0[k] + bg[1] * dp1[k] + bg[2] * dp2[k];
-    Tr[k] = T_final[k];
-    ar0[k] = ar1[k] = ar2[k] = lc0[k] = lc1[k] = lc2[k] = last_alpha[k] = ainv[k] = linv[k] = 0.f;
-    wmax = max(wmax, last[k]);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o));
+  {
+    const int tile = (int)lid - view * T;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int px = tx * U3D_TILE + (lane & 15);
+    const int py0 = ty * U3D_TILE + (lane >> 4);
+    const float pxf = (float)px;
+    const size_t vbase = (size_t)view * P;
+    const size_t npix = (size_t)H * W;
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
-  const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
-  for (int b = nb - 1; b >= 0; --b) {
-    const uint32_t s = (uint32_t)b * U3D_WAVE + (uint32_t)lane;
-    bool hit = false;
-    if (s < wmax) hit = rect_hits(sorted_rect[vbase + s], tx, ty);
-    const unsigned long long bal = __ballot(hit);
-    const int total = __popcll(bal);
-    if (total == 0) continue;
-    if (hit) {
-      const uint32_t o = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-      const uint32_t id = sorted_id[vbase + s];
-      const size_t g = vbase + id;
-      const float2 m = xy[g];
-      const float4 co = conic_op[g];
-      const float4 cd = rgbd[g];
-      sA[wave][o] = make_float4(m.x, m.y, co.x, co.y);
-      sB[wave][o] = make_float4(co.z, co.w, 1.0f / cd.w, __uint_as_float(s + 1u));
-      sC[wave][o] = make_float4(cd.x, cd.y, cd.z, __uint_as_float(id));
-    }
+    float T_final[4], Tr[4], dp0[4], dp1[4], dp2[4], dinv[4], bg_dot[4], pyf[4];
+    float ar0[4], ar1[4], ar2[4], lc0[4], lc1[4], lc2[4], last_alpha[4], ainv[4], linv[4];
+    uint32_t last[4];
+    uint32_t wmax = 0;
 #pragma unroll
-    for (int k = 0; k < U3D_NACC; ++k) sAcc[wave][k][lane] = 0.f;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int j = total - 1; j >= 0; --j) {
-      const float4 A = sA[wave][j];
-      const float4 B = sB[wave][j];
-      const float4 Cc = sC[wave][j];
-      const uint32_t pos = __float_as_uint(B.w);
-      const float dx = A.x - pxf;
-      float m0 = 0.f, mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
-      bool any = false;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float dy = A.y - pyf[k];
-        const float pw = fmaf(-0.5f * LOG2E * A.z * dx, dx, fmaf(-0.5f * LOG2E * B.x * dy, dy, -LOG2E * A.w * dx * dy));
-        const float G = __builtin_amdgcn_exp2f(pw);
-        const float alpha = fminf(0.99f, B.y * G);
-        const bool ok = pos <= last[k] && pw <= 0.f && alpha >= ALPHA_MIN;
-        if (ok) {
-          any = true;
-          const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
-          Tr[k] = Tr[k] * rc;
-          const float w = alpha * Tr[k];
-          const float la = last_alpha[k];
-          ar0[k] = la * lc0[k] + (1.f - la) * ar0[k]; lc0[k] = Cc.x;
-          ar1[k] = la * lc1[k] + (1.f - la) * ar1[k]; lc1[k] = Cc.y;
-          ar2[k] = la * lc2[k] + (1.f - la) * ar2[k]; lc2[k] = Cc.z;
-          float dL_dalpha = (Cc.x - ar0[k]) * dp0[k] + (Cc.y - ar1[k]) * dp1[k] + (Cc.z - ar2[k]) * dp2[k];
-          g_r = fmaf(w, dp0[k], g_r); g_g = fmaf(w, dp1[k], g_g); g_b = fmaf(w, dp2[k], g_b);
-          if (HAS_INVD) {
-            ainv[k] = la * linv[k] + (1.f - la) * ainv[k]; linv[k] = B.z;
-            dL_dalpha += (B.z - ainv[k]) * dinv[k];
-            g_d = fmaf(w, dinv[k], g_d);
+    for (int k = 0; k < 4; ++k) {
+      const int py = py0 + 4 * k;
+      pyf[k] = (float)py;
+      const bool inside = px < W && py < H;
+      const size_t pid = (size_t)py * W + px;
+      T_final[k] = inside ? final_T[(size_t)view * npix + pid] : 0.f;
+      last[k] = inside ? n_contrib[(size_t)view * npix + pid] : 0u;
+      dp0[k] = dp1[k] = dp2[k] = dinv[k] = 0.f;
+      if (inside) {
+        if (loss.kind != 0) {
+          const float* xp = out_color + (size_t)view * 3 * npix + pid;
+          const float* gp = loss.gt + (size_t)view * 3 * npix + pid;
+          const float g0 = gp[0], g1 = gp[npix], g2 = gp[2 * npix];
+          const float d0 = xp[0] - g0, d1 = xp[npix] - g1, d2 = xp[2 * npix] - g2;
+          const float sc = loss.dloss[0] * loss.inv_count;
+          if (loss.kind == 3) {
+            dp0[k] = sc * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
+            dp1[k] = sc * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+            dp2[k] = sc * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
+          } else {
+            const float w2 = 2.f * sc * focal_weight(loss, bg, g0, g1, g2);
+            dp0[k] = w2 * d0; dp1[k] = w2 * d1; dp2[k] = w2 * d2;
           }
-          dL_dalpha *= Tr[k];
-          last_alpha[k] = alpha;
-          dL_dalpha += (-T_final[k] * rc) * bg_dot[k];
-          const float q = B.y * dL_dalpha * G;    // dL/dG * G
-          const float qdx = q * dx, qdy = q * dy;
-          m0 += q; mx += qdx; my += qdy;
-          mxx = fmaf(qdx, dx, mxx); mxy = fmaf(qdx, dy, mxy); myy = fmaf(qdy, dy, myy);
+        } else {
+          const float* dc = dL_dcolor + (size_t)view * 3 * npix + pid;
+          dp0[k] = dc[0]; dp1[k] = dc[npix]; dp2[k] = dc[2 * npix];
+          if (HAS_INVD) dinv[k] = dL_dinvdepth[(size_t)view * npix + pid];
         }
       }
-      if (__ballot(any) == 0ull) continue;
-      m0 = wave_sum_to_lane63(m0); mx = wave_sum_to_lane63(mx); my = wave_sum_to_lane63(my);
-      mxx = wave_sum_to_lane63(mxx); mxy = wave_sum_to_lane63(mxy); myy = wave_sum_to_lane63(myy);
-      g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
-      if (HAS_INVD) g_d = wave_sum_to_lane63(g_d);
-      if (lane == 63) {
-        sAcc[wave][0][j] = -ddelx_dx * (A.z * mx + A.w * my);
-        sAcc[wave][1][j] = -ddely_dy * (B.x * my + A.w * mx);
-        sAcc[wave][2][j] = -0.5f * mxx;
-        sAcc[wave][3][j] = -0.5f * mxy;
-        sAcc[wave][4][j] = -0.5f * myy;
-        sAcc[wave][5][j] = m0 / B.y;
-        sAcc[wave][6][j] = g_r; sAcc[wave][7][j] = g_g; sAcc[wave][8][j] = g_b;
-        if (HAS_INVD) sAcc[wave][9][j] = g_d;
-      }
+      bg_dot[k] = bg[0] * dp0[k] + bg[1] * dp1[k] + bg[2] * dp2[k];
+      Tr[k] = T_final[k];
+      ar0[k] = ar1[k] = ar2[k] = lc0[k] = lc1[k] = lc2[k] = last_alpha[k] = ainv[k] = linv[k] = 0.f;
+      wmax = max(wmax, last[k]);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < total) {
-      const size_t g = vbase + __float_as_uint(sC[wave][lane].w);
 #pragma unroll
-      for (int k = 0; k < (HAS_INVD ? U3D_NACC : U3D_NACC - 1); ++k) {
-        const float v = sAcc[wave][k][lane];
-        if (v != 0.f) unsafeAtomicAdd(&acc[(size_t)k * NG + g], v);
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o));
+
+    const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
+    for (int b = nb - 1; b >= 0; --b) {
+      const uint32_t s = (uint32_t)b * U3D_WAVE + (uint32_t)lane;
+      bool hit = false;
+      if (s < wmax) hit = rect_hits(sorted_rect[vbase + s], tx, ty);
+      const unsigned long long bal = __ballot(hit);
+      const int total = __popcll(bal);
+      if (total == 0) continue;
+      if (hit) {
+        const uint32_t o = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        const uint32_t id = sorted_id[vbase + s];
+        const size_t g = vbase + id;
+        const float2 m = xy[g];
+        const float4 co = conic_op[g];
+        const float4 cd = rgbd[g];
+        sA[wave][o] = make_float4(m.x, m.y, co.x, co.y);
+        sB[wave][o] = make_float4(co.z, co.w, 1.0f / cd.w, __uint_as_float(s + 1u));
+        sC[wave][o] = make_float4(cd.x, cd.y, cd.z, __uint_as_float(id));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int j = total - 1; j >= 0; --j) {
+        const float4 A = sA[wave][j];
+        const float4 B = sB[wave][j];
+        const float4 Cc = sC[wave][j];
+        const uint32_t pos = __float_as_uint(B.w);
+        const float dx = A.x - pxf;
+        float m0 = 0.f, mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float dy = A.y - pyf[k];
+          const float pw = fmaf(-0.5f * LOG2E * A.z * dx, dx, fmaf(-0.5f * LOG2E * B.x * dy, dy, -LOG2E * A.w * dx * dy));
+          const float G = __builtin_amdgcn_exp2f(pw);
+          const float alpha = fminf(0.99f, B.y * G);
+          const bool ok = pos <= last[k] && pw <= 0.f && alpha >= ALPHA_MIN;
+          if (ok) {
+            any = true;
+            const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
+            Tr[k] = Tr[k] * rc;
+            const float w = alpha * Tr[k];
+            const float la = last_alpha[k];
+            ar0[k] = la * lc0[k] + (1.f - la) * ar0[k]; lc0[k] = Cc.x;
+            ar1[k] = la * lc1[k] + (1.f - la) * ar1[k]; lc1[k] = Cc.y;
+            ar2[k] = la * lc2[k] + (1.f - la) * ar2[k]; lc2[k] = Cc.z;
+            float dL_dalpha = (Cc.x - ar0[k]) * dp0[k] + (Cc.y - ar1[k]) * dp1[k] + (Cc.z - ar2[k]) * dp2[k];
+            g_r = fmaf(w, dp0[k], g_r); g_g = fmaf(w, dp1[k], g_g); g_b = fmaf(w, dp2[k], g_b);
+            if (HAS_INVD) {
+              ainv[k] = la * linv[k] + (1.f - la) * ainv[k]; linv[k] = B.z;
+              dL_dalpha += (B.z - ainv[k]) * dinv[k];
+              g_d = fmaf(w, dinv[k], g_d);
+            }
+            dL_dalpha *= Tr[k];
+            last_alpha[k] = alpha;
+            dL_dalpha += (-T_final[k] * rc) * bg_dot[k];
+            const float q = B.y * dL_dalpha * G;    // dL/dG * G
+            const float qdx = q * dx, qdy = q * dy;
+            m0 += q; mx += qdx; my += qdy;
+            mxx = fmaf(qdx, dx, mxx); mxy = fmaf(qdx, dy, mxy); myy = fmaf(qdy, dy, myy);
+          }
+        }
+        if (__ballot(any) == 0ull) continue;
+        m0 = wave_sum_to_lane63(m0); mx = wave_sum_to_lane63(mx); my = wave_sum_to_lane63(my);
+        mxx = wave_sum_to_lane63(mxx); mxy = wave_sum_to_lane63(mxy); myy = wave_sum_to_lane63(myy);
+        g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+        if (HAS_INVD) g_d = wave_sum_to_lane63(g_d);
+        if (lane == 63) {
+          // batch 0 is indexed by sorted position (merged across tiles below), later batches by compaction slot
+          const int slot = b == 0 ? (int)pos - 1 : j;
+          sAcc[wave][0][slot] = -ddelx_dx * (A.z * mx + A.w * my);
+          sAcc[wave][1][slot] = -ddely_dy * (B.x * my + A.w * mx);
+          sAcc[wave][2][slot] = -0.5f * mxx;
+          sAcc[wave][3][slot] = -0.5f * mxy;
+          sAcc[wave][4][slot] = -0.5f * myy;
+          sAcc[wave][5][slot] = m0 / B.y;
+          sAcc[wave][6][slot] = g_r; sAcc[wave][7][slot] = g_g; sAcc[wave][8][slot] = g_b;
+          if (HAS_INVD) sAcc[wave][9][slot] = g_d;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (b > 0) {
+        if (lane < total) {
+          const size_t g = vbase + __float_as_uint(sC[wave][lane].w);
+#pragma unroll
+          for (int k = 0; k < NK; ++k) {
+            const float v = sAcc[wave][k][lane];
+            if (v != 0.f) unsafeAtomicAdd(&acc[(size_t)k * NG + g], (double)v);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) sAcc[wave][k][lane] = 0.f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
+  // positions 0..63 of this tile: plain coalesced stores, reduced over the tiles by bwd_reduce_kernel
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float* pt = part + (size_t)lid * (U3D_NACC * U3D_WAVE);
+#pragma unroll
+  for (int k = 0; k < NK; ++k) pt[k * U3D_WAVE + lane] = sAcc[wave][k][lane];
+}
+
+// acc[k][view*P + sorted_id[sp]] += sum over the view's tiles (ascending) of part[view][tile][k][sp], in f64.
+__global__ __launch_bounds__(U3D_NACC * U3D_WAVE) void bwd_reduce_kernel(int P, int T, int NK, size_t NG,
+                                                                        const uint32_t* __restrict__ sorted_id,
+                                                                        const uint32_t* __restrict__ n_vis,
+                                                                        const float* __restrict__ part,
+                                                                        double* __restrict__ acc) {
+  const int view = blockIdx.x, k = threadIdx.x >> 6, sp = threadIdx.x & 63;
+  if (k >= NK || (uint32_t)sp >= n_vis[view]) return;
+  const float* p = part + (size_t)view * T * (U3D_NACC * U3D_WAVE) + k * U3D_WAVE + sp;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int t = 0;
+  for (; t + 3 < T; t += 4) {
+    a0 += (double)p[(size_t)t * (U3D_NACC * U3D_WAVE)];
+    a1 += (double)p[(size_t)(t + 1) * (U3D_NACC * U3D_WAVE)];
+    a2 += (double)p[(size_t)(t + 2) * (U3D_NACC * U3D_WAVE)];
+    a3 += (double)p[(size_t)(t + 3) * (U3D_NACC * U3D_WAVE)];
+  }
+  for (; t < T; ++t) a0 += (double)p[(size_t)t * (U3D_NACC * U3D_WAVE)];
+  const double a = (a0 + a1) + (a2 + a3);
+  if (a != 0.0) acc[(size_t)k * NG + (size_t)view * P + sorted_id[(size_t)view * P + sp]] += a;
 }
 
 // Fixed-order sum of the per-tile partials (deterministic): 1024 threads, 4 independent accumulators each.
@@ -528,14 +692,22 @@ void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   const int T = tiles_x * tiles_y;
   const uint32_t nblocks = (uint32_t)(d.n_items * d.views_per_item * T);
   if (nblocks == 0) return;
+  static const bool use_v1 = getenv("U3D_FWD_V1") != nullptr;   // A/B switch for measurements
+  if (!use_v1) {
+    const uint32_t nwg = (nblocks + 3u) / 4u;
+    hipLaunchKernelGGL(render_fwd_wave_kernel, dim3(nwg), dim3(U3D_BLOCK), 0, s, d.P, d.image_height, d.image_width, tiles_x, T,
+                       nblocks, nwg, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color, out_invdepth,
+                       b.final_T, b.n_contrib, loss);
+    return;
+  }
   hipLaunchKernelGGL(render_fwd_kernel, dim3(nblocks), dim3(U3D_BLOCK), 0, s, d.P, d.image_height, d.image_width,
                      tiles_x, T, nblocks, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
                      out_invdepth, b.final_T, b.n_contrib, loss);
 }
 
 void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, const float* dL_dcolor,
-                           const float* dL_dinvdepth, const float* out_color, const U3DLoss& loss, float* acc,
-                           hipStream_t s) {
+                           const float* dL_dinvdepth, const float* out_color, const U3DLoss& loss, double* acc,
+                           float* part, hipStream_t s) {
   const int tiles_x = (d.image_width + U3D_TILE - 1) / U3D_TILE, tiles_y = (d.image_height + U3D_TILE - 1) / U3D_TILE;
   const int T = tiles_x * tiles_y;
   const uint32_t nblocks = (uint32_t)(d.n_items * d.views_per_item * T);
@@ -543,15 +715,18 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   if (nblocks == 0 || NG == 0) return;
   static const bool use_v1 = getenv("U3D_BWD_V1") != nullptr;   // A/B switch for measurements
   if (!use_v1) {
-    const uint32_t nwg = (nblocks + 3u) / 4u;
+    const uint32_t nwg = (nblocks + BWD_WAVES - 1u) / BWD_WAVES;
     if (dL_dinvdepth && loss.kind == 0)
-      hipLaunchKernelGGL(render_bwd_wave_kernel<true>, dim3(nwg), dim3(U3D_BLOCK), 0, s, d.P, d.image_height, d.image_width,
+      hipLaunchKernelGGL(render_bwd_wave_kernel<true>, dim3(nwg), dim3(BWD_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
                          tiles_x, T, nblocks, nwg, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg, dL_dcolor,
-                         dL_dinvdepth, b.final_T, b.n_contrib, acc, out_color, loss);
+                         dL_dinvdepth, b.final_T, b.n_contrib, acc, part, out_color, loss);
     else
-      hipLaunchKernelGGL(render_bwd_wave_kernel<false>, dim3(nwg), dim3(U3D_BLOCK), 0, s, d.P, d.image_height, d.image_width,
+      hipLaunchKernelGGL(render_bwd_wave_kernel<false>, dim3(nwg), dim3(BWD_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
                          tiles_x, T, nblocks, nwg, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg, dL_dcolor,
-                         dL_dinvdepth, b.final_T, b.n_contrib, acc, out_color, loss);
+                         dL_dinvdepth, b.final_T, b.n_contrib, acc, part, out_color, loss);
+    const bool invd = dL_dinvdepth && loss.kind == 0;
+    hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item), dim3(U3D_NACC * U3D_WAVE), 0, s, d.P, T,
+                       invd ? U3D_NACC : U3D_NACC - 1, NG, b.sorted_id, b.n_vis, part, acc);
     return;
   }
   hipLaunchKernelGGL(render_bwd_kernel, dim3(nblocks), dim3(U3D_BLOCK), 0, s, d.P, d.image_height, d.image_width,
