@@ -167,7 +167,7 @@ int u3d_rasterize_forward(const u3d_raster_desc* desc, const float* bg, const fl
   U3DBuffers b{};
   u3d_carve(d, geom, binning, image, &b);
   (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
-  (void)hipMemsetAsync(b.n_vis, 0, sizeof(uint32_t) * NV, s);
+  if (d.P == 0) (void)hipMemsetAsync(b.n_vis, 0, sizeof(uint32_t) * NV, s);   // the sort writes n_vis whenever P > 0
   if (d.P > 0) {
     {
       ProfScope ps(0, s);
@@ -248,7 +248,6 @@ int u3d_render_loss_forward(const u3d_raster_desc* desc, const u3d_head_desc* he
   U3DFused f{};
   u3d_carve_fused(d, fused, &f);
   (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
-  (void)hipMemsetAsync(b.n_vis, 0, sizeof(uint32_t) * NV, s);
   if (head->mode == 1) u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, s);
   {
     ProfScope ps(0, s);

@@ -143,7 +143,7 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
   L.acc_bytes = u3d_align(sizeof(double) * U3D_NACC * (NG > 0 ? NG : 1));
   {
     const size_t Tn = (size_t)((d.image_width + U3D_TILE - 1) / U3D_TILE) * ((d.image_height + U3D_TILE - 1) / U3D_TILE);
-    L.backward_bytes = L.acc_bytes + u3d_align(sizeof(float) * U3D_NACC * U3D_WAVE * (NV * Tn > 0 ? NV * Tn : 1));
+    L.backward_bytes = L.acc_bytes + u3d_align(sizeof(float) * (U3D_NACC * U3D_WAVE + 16) * (NV * Tn > 0 ? NV * Tn : 1));
   }
   L.fused_bytes = u3d_carve_fused(d, nullptr, nullptr);
   return L;

@@ -262,9 +262,11 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const double* __restrict__ acc,
     U3DGradSink sink) {
+  // 4 consecutive lanes (a DPP quad) share one Gaussian and split its views: lane&3 = view slot
   __shared__ float s_qdot[4][4];
   const int item = blockIdx.y;
-  const int i = blockIdx.x * U3D_BLOCK + threadIdx.x;
+  const int vslot = threadIdx.x & 3;
+  const int i = blockIdx.x * (U3D_BLOCK / 4) + (threadIdx.x >> 2);
   const bool alive = i < P;
   const size_t gi = (size_t)item * P + (alive ? i : 0);
   GaussIn gin;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
   for (int k = 0; k < K * 3; ++k) dsh[k] = 0.f;
   const float fx = (float)W / (2.f * tanx), fy = (float)H / (2.f * tany);
 
-  for (int vk = 0; vk < (alive ? vpi : 0); ++vk) {
+  for (int vk = vslot; vk < (alive ? vpi : 0); vk += 4) {
     const int view = item * vpi + vk;
     const size_t g = (size_t)view * P + i;
     const bool live = radii[g] > 0;
@@ -440,6 +442,18 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     }
   }
 
+  // ---- sum the quad's view slots (two xor steps inside the DPP quad) ----
+#define QUAD_SUM(v) do { (v) += __shfl_xor((v), 1); (v) += __shfl_xor((v), 2); } while (0)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { QUAD_SUM(dmean[k]); QUAD_SUM(dcol[k]); }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) QUAD_SUM(dcov[k]);
+  QUAD_SUM(dop);
+#pragma unroll
+  for (int k = 0; k < K * 3; ++k) QUAD_SUM(dsh[k]);
+#undef QUAD_SUM
+  const bool writer = alive && vslot == 0;
+
   // ---- outputs (strided like the source); act != 0 chains through the head activations ----
   float drot[4] = {0.f, 0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f};
   if (src.scales) {
@@ -473,7 +487,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     drot[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
   }
   float qd[4] = {0.f, 0.f, 0.f, 0.f};
-  if (alive) {
+  if (writer) {
     if (src.act != 0) {
       // tanh, sigmoid, exp(clamp) derivatives (model/gaussian_predictor.py:249-254)
 #pragma unroll
@@ -605,7 +619,7 @@ void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, co
                                const float* projmatrix, const float* campos, const int32_t* radii, const double* acc,
                                const U3DGradSink& sink, hipStream_t s) {
   const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
-  dim3 grid((d.P + U3D_BLOCK - 1) / U3D_BLOCK, d.n_items), block(U3D_BLOCK);
+  dim3 grid((d.P + U3D_BLOCK / 4 - 1) / (U3D_BLOCK / 4), d.n_items), block(U3D_BLOCK);
   const int D = src.shs ? d.sh_degree : 0;
 #define LAUNCH(DEG)                                                                                                    \
   hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, d.P, d.views_per_item, d.sh_coeffs, d.image_height, \

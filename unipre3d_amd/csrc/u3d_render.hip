@@ -460,9 +460,11 @@ __global__ __launch_bounds__(U3D_BLOCK) void render_bwd_kernel(
 // (sparse / semi-transparent scenes) fall back to f64 global atomics, whose ordering does not show at fp32 output
 // precision.  The result is therefore run-to-run deterministic, unlike the original's fp32 atomics.
 constexpr int BWD_WAVES = 4;
+constexpr int BWD_PART_STRIDE = U3D_NACC * U3D_WAVE + 16;   // floats per tile slot (+ row count, 64-B aligned)
+constexpr int BWD_REDUCE_SPLIT = 8;                          // workgroups per view in bwd_reduce_kernel
 
 template <bool HAS_INVD>
-__global__ __launch_bounds__(BWD_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
+__global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_bwd_wave_kernel(
     int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t nblocks, size_t NG,
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const float2* __restrict__ xy,
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
@@ -481,6 +483,7 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
   const int view = (int)(lid / T);
 #pragma unroll
   for (int k = 0; k < NK; ++k) sAcc[wave][k][lane] = 0.f;
+  uint32_t wmax_all = 0;
 
   {
     const int tile = (int)lid - view * T;
@@ -534,6 +537,7 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o));
 
+    wmax_all = wmax;
     const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
     for (int b = nb - 1; b >= 0; --b) {
       const uint32_t s = (uint32_t)b * U3D_WAVE + (uint32_t)lane;
@@ -634,31 +638,43 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
   // positions 0..63 of this tile: plain coalesced stores, reduced over the tiles by bwd_reduce_kernel
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  float* pt = part + (size_t)lid * (U3D_NACC * U3D_WAVE);
+  // (only the rows this tile can have touched: positions < min(wmax, 64); the count is the last word of the slot)
+  float* pt = part + (size_t)lid * BWD_PART_STRIDE;
+  const uint32_t cnt = min(wmax_all, (uint32_t)U3D_WAVE);
+  if ((uint32_t)lane < cnt) {
 #pragma unroll
-  for (int k = 0; k < NK; ++k) pt[k * U3D_WAVE + lane] = sAcc[wave][k][lane];
+    for (int k = 0; k < NK; ++k) pt[k * U3D_WAVE + lane] = sAcc[wave][k][lane];
+  }
+  if (lane == 0) reinterpret_cast<uint32_t*>(pt)[U3D_NACC * U3D_WAVE] = cnt;
 }
 
-// acc[k][view*P + sorted_id[sp]] += sum over the view's tiles (ascending) of part[view][tile][k][sp], in f64.
+// acc[k][view*P + sorted_id[sp]] += sum over a slice of the view's tiles (ascending) of part[tile][k][sp], in f64;
+// the BWD_REDUCE_SPLIT slices of a view meet in an f64 atomic (order-insensitive at fp32 output precision).
 __global__ __launch_bounds__(U3D_NACC * U3D_WAVE) void bwd_reduce_kernel(int P, int T, int NK, size_t NG,
                                                                         const uint32_t* __restrict__ sorted_id,
-                                                                        const uint32_t* __restrict__ n_vis,
                                                                         const float* __restrict__ part,
                                                                         double* __restrict__ acc) {
   const int view = blockIdx.x, k = threadIdx.x >> 6, sp = threadIdx.x & 63;
-  if (k >= NK || (uint32_t)sp >= n_vis[view]) return;
-  const float* p = part + (size_t)view * T * (U3D_NACC * U3D_WAVE) + k * U3D_WAVE + sp;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int t = 0;
-  for (; t + 3 < T; t += 4) {
-    a0 += (double)p[(size_t)t * (U3D_NACC * U3D_WAVE)];
-    a1 += (double)p[(size_t)(t + 1) * (U3D_NACC * U3D_WAVE)];
-    a2 += (double)p[(size_t)(t + 2) * (U3D_NACC * U3D_WAVE)];
-    a3 += (double)p[(size_t)(t + 3) * (U3D_NACC * U3D_WAVE)];
+  if (k >= NK) return;
+  const int per = (T + BWD_REDUCE_SPLIT - 1) / BWD_REDUCE_SPLIT;
+  const int t0 = blockIdx.y * per, t1 = min(T, t0 + per);
+  const float* base = part + (size_t)view * T * BWD_PART_STRIDE;
+  double a0 = 0.0, a1 = 0.0;
+  int t = t0;
+  for (; t + 1 < t1; t += 2) {
+    const float* p0 = base + (size_t)t * BWD_PART_STRIDE;
+    const float* p1 = p0 + BWD_PART_STRIDE;
+    const uint32_t c0 = reinterpret_cast<const uint32_t*>(p0)[U3D_NACC * U3D_WAVE];
+    const uint32_t c1 = reinterpret_cast<const uint32_t*>(p1)[U3D_NACC * U3D_WAVE];
+    if ((uint32_t)sp < c0) a0 += (double)p0[k * U3D_WAVE + sp];
+    if ((uint32_t)sp < c1) a1 += (double)p1[k * U3D_WAVE + sp];
   }
-  for (; t < T; ++t) a0 += (double)p[(size_t)t * (U3D_NACC * U3D_WAVE)];
-  const double a = (a0 + a1) + (a2 + a3);
-  if (a != 0.0) acc[(size_t)k * NG + (size_t)view * P + sorted_id[(size_t)view * P + sp]] += a;
+  if (t < t1) {
+    const float* p0 = base + (size_t)t * BWD_PART_STRIDE;
+    if ((uint32_t)sp < reinterpret_cast<const uint32_t*>(p0)[U3D_NACC * U3D_WAVE]) a0 += (double)p0[k * U3D_WAVE + sp];
+  }
+  const double a = a0 + a1;
+  if (a != 0.0) unsafeAtomicAdd(&acc[(size_t)k * NG + (size_t)view * P + sorted_id[(size_t)view * P + sp]], a);
 }
 
 // Fixed-order sum of the per-tile partials (deterministic): 1024 threads, 4 independent accumulators each.
@@ -725,8 +741,8 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
                          tiles_x, T, nblocks, nwg, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg, dL_dcolor,
                          dL_dinvdepth, b.final_T, b.n_contrib, acc, part, out_color, loss);
     const bool invd = dL_dinvdepth && loss.kind == 0;
-    hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item), dim3(U3D_NACC * U3D_WAVE), 0, s, d.P, T,
-                       invd ? U3D_NACC : U3D_NACC - 1, NG, b.sorted_id, b.n_vis, part, acc);
+    hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, BWD_REDUCE_SPLIT), dim3(U3D_NACC * U3D_WAVE), 0, s,
+                       d.P, T, invd ? U3D_NACC : U3D_NACC - 1, NG, b.sorted_id, part, acc);
     return;
   }
   hipLaunchKernelGGL(render_bwd_kernel, dim3(nblocks), dim3(U3D_BLOCK), 0, s, d.P, d.image_height, d.image_width,

@@ -48,6 +48,7 @@ class _RenderLossFn(torch.autograd.Function):
         ctx.plan, ctx.hd, ctx.ld = plan, hd, ld
         ctx.save_for_backward(head_out, center, viewmatrix, projmatrix, campos, gt, bg, color, radii, geom, binning, image, fused)
         ctx.mark_non_differentiable(color, radii)
+        ctx.set_materialize_grads(False)
         return loss, color, radii
 
     @staticmethod
@@ -55,6 +56,8 @@ class _RenderLossFn(torch.autograd.Function):
         lib = _lib.load()
         head_out, center, viewmatrix, projmatrix, campos, gt, bg, color, radii, geom, binning, image, fused = ctx.saved_tensors
         dev = head_out.device
+        if grad_loss is None:
+            return (torch.zeros_like(head_out),) + (None,) * 17
         d_head = torch.empty_like(head_out)
         scratch = torch.empty(ctx.plan.sizes.backward_bytes, dtype=torch.uint8, device=dev)
         dloss = _f32c(grad_loss, dev).reshape(1)

@@ -107,6 +107,7 @@ class _RasterizeFn(torch.autograd.Function):
         ctx.save_for_backward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
                               projmatrix, campos, bg, radii, geom, binning, image)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # unused outputs (invdepth) arrive as None, not as a zero tensor
         return color, radii, invdepth
 
     @staticmethod
@@ -118,6 +119,8 @@ class _RasterizeFn(torch.autograd.Function):
         d = plan.desc
         dev = means3D.device
         NV, P, M = d.n_items * d.views_per_item, d.P, d.sh_coeffs
+        if grad_color is None:      # only the inverse-depth output was used downstream
+            grad_color = torch.zeros((NV, 3, d.image_height, d.image_width), dtype=torch.float32, device=dev)
         grad_color = _f32c(grad_color, dev)
         grad_invdepth = _f32c(grad_invdepth, dev) if grad_invdepth is not None else None
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
