@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the render-loss hot path on MI355X (contract: see DESIGN.md section "Measurement").
 
-A step = one pass of the hot path over one synthetic batch resident in HBM:
-  Gaussian head (PyTorch, the reference's `final` MLP) -> head activations (R1) -> batched HIP rasterizer forward
-  (R4/R7) -> focal-L2 render loss (R8) -> HIP rasterizer backward (R5) -> head backward -> [DDP gradient
-  all-reduce over RCCL when N > 1 (R9)] -> grad clip -> AdamW step.
+A step = one pass of the hot path over one synthetic batch resident in HBM (SURVEY section 8 rows R1, R7/R2/R4, R8, R5):
+  raw Gaussian-head output (B,P,23) -> head activations -> batched HIP rasterizer forward over all B*V views ->
+  focal-L2 render loss -> HIP rasterizer backward -> dL/d(head output).   This is what `value` times.
+A second timed region (reported under "train_step_with_head", not `value`) wraps the same path in a trainable module:
+  Gaussian head (the reference's `final` MLP, PyTorch) -> hot path -> head backward -> [DDP gradient all-reduce over
+  RCCL when N > 1 (R9)] -> grad clip -> AdamW, so that the one real exchange step of the path is exercised on GPUs.
 Workload at N=1: BASELINE.json configs[1] (C2): transformer config, 128 Gaussians per object (1024 pts -> 128
 groups), 256x256, batch 32 per GPU x 4 supervised views = 128 rendered views per step.  Weak scaling: every
 rank renders its own 32 objects.  Prints ONE JSON line on rank 0.
@@ -121,25 +123,46 @@ def main():
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, eps=1e-15, fused=True)  # train_network.py:156-158 (group lr 1e-4)
     loss_kind = "focal_l2" if level == "object" else "l2"
 
-    def one_step():
+    from unipre3d_amd.fused import render_loss_fused
+    head_out = model.module(feats, point_major=True).detach() if world > 1 else model(feats, point_major=True).detach()
+    head_out = head_out.contiguous().requires_grad_(True)      # (B,P,23): the raw head output the hot path starts from
+
+    def hot_step():
+        """R1 -> R7/R2/R4 -> R8 -> R5: loss and dL/d(head output)."""
+        head_out.grad = None
+        if a.unfused:
+            loss, _ = step.render_loss_forward(head_out.permute(0, 2, 1), batch, H, W, 0, loss_kind)
+        else:
+            loss, _, _ = render_loss_fused(head_out, batch.center, batch.world_view, batch.full_proj, batch.camera_center, batch.gt,
+                                           batch.bg, batch.fov_deg, H, W, level=level, offset_scale=batch.offset_scale,
+                                           loss_kind=loss_kind)
+        loss.backward()
+        return loss.detach()
+
+    def train_step():
         return step.train_step(model, feats, batch, opt, H, W, 0, loss_kind, fused=not a.unfused)
 
-    for _ in range(a.warmup):
-        one_step()
-    dp.synchronize()
-    torch.cuda.synchronize()
-    _lib.profile_begin(8 * (a.steps + 2) * 8)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = one_step()
-    torch.cuda.synchronize()
-    dp.synchronize()
-    t1 = time.perf_counter()
-    prof = _lib.profile_end()
-    elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = elapsed.item()
+    def timed(fn, profile):
+        for _ in range(a.warmup):
+            fn()
+        dp.synchronize()
+        torch.cuda.synchronize()
+        if profile:
+            _lib.profile_begin(8 * (a.steps + 2) * 8)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = fn()
+        torch.cuda.synchronize()
+        dp.synchronize()
+        t1 = time.perf_counter()
+        prof = _lib.profile_end() if profile else None
+        el = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return el.item(), prof, out
+
+    elapsed, prof, loss = timed(hot_step, True)
+    elapsed_train, _, loss_train = timed(train_step, False)
 
     # statistics of the workload (outside the timed region): R = num_rendered
     from unipre3d_amd.rasterizer import _RasterizeFn  # noqa: F401
@@ -175,12 +198,16 @@ def main():
             "metric": "rendered_views_per_sec", "value": world * NV * a.steps / elapsed, "unit": "views/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.config}: render-loss step, {level}-level, P={P} Gaussians/object, {H}x{W}, "
+            "config": {"workload": f"{a.config}: render-loss hot path (activations + render fwd + loss + render bwd), {level}-level, P={P} Gaussians/object, {H}x{W}, "
                                    f"B={B}/GPU x V={V} views = {NV} renders/GPU/step" + (" (compact splats)" if a.compact else ""),
                        "global_batch": B * world, "views_per_step": NV * world, "parallelism": f"dp{world}",
                        "loss": loss_kind, "num_rendered_per_view": R_mean,
                        "path": "unfused (torch activations/loss)" if a.unfused else "fused head-activation + render + loss (HIP)"},
             "render_loss_step_ms": {"rasterizer_fwd_kernels": fwd_ms, "rasterizer_bwd_kernels": bwd_ms, "kernels": kernels},
+            "train_step_with_head": {"value": world * NV * a.steps / elapsed_train, "unit": "views/s",
+                                     "ms_per_step": 1e3 * elapsed_train / a.steps,
+                                     "what": "Gaussian head MLP fwd/bwd + hot path + " + ("DDP all-reduce (RCCL) + " if world > 1 else "")
+                                             + "clip_grad_norm + AdamW", "final_loss": float(loss_train)},
             "final_loss": float(loss),
         }
         if dom:
