@@ -600,9 +600,24 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_bwd_wave_kerne
           }
         }
         if (__ballot(any) == 0ull) continue;
-        m0 = wave_sum_to_lane63(m0); mx = wave_sum_to_lane63(mx); my = wave_sum_to_lane63(my);
-        mxx = wave_sum_to_lane63(mxx); mxy = wave_sum_to_lane63(mxy); myy = wave_sum_to_lane63(myy);
-        g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+        // nine interleaved wave reductions, one v_add_f32_dpp per value and level (hipcc does not fuse
+        // update_dpp + fadd: -0.0 rule); interleaving keeps dependent DPP ops >= 8 instructions apart, so the
+        // VALU-write -> DPP-read hazard needs no wait states inside the asm.
+#define U3D_DPP9(CTRL)                                                                                              \
+  asm volatile("s_nop 1\n\t"                                                                                        \
+               "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\t"                        \
+               "v_add_f32_dpp %2, %2, %2 " CTRL "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\t"                        \
+               "v_add_f32_dpp %4, %4, %4 " CTRL "\n\tv_add_f32_dpp %5, %5, %5 " CTRL "\n\t"                        \
+               "v_add_f32_dpp %6, %6, %6 " CTRL "\n\tv_add_f32_dpp %7, %7, %7 " CTRL "\n\t"                        \
+               "v_add_f32_dpp %8, %8, %8 " CTRL "\n\ts_nop 1"                                                       \
+               : "+v"(m0), "+v"(mx), "+v"(my), "+v"(mxx), "+v"(mxy), "+v"(myy), "+v"(g_r), "+v"(g_g), "+v"(g_b))
+        U3D_DPP9("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+        U3D_DPP9("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+        U3D_DPP9("row_half_mirror row_mask:0xf bank_mask:0xf");
+        U3D_DPP9("row_mirror row_mask:0xf bank_mask:0xf");
+        U3D_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf");
+        U3D_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef U3D_DPP9
         if (HAS_INVD) g_d = wave_sum_to_lane63(g_d);
         if (lane == 63) {
           // batch 0 is indexed by sorted position (merged across tiles below), later batches by compaction slot
