@@ -36,6 +36,7 @@ def algorithmic_bytes(kind: str, P: int, R: float, T: int, HW: int) -> float:
         "preprocess_fwd": 168.0 * P,
         "depth_sort": 36.0 * R,               # key/value write 12 + sort read 12 + sort write 12 of the reference algorithm
         "render_fwd": 40.0 * R + 8.0 * T + 24.0 * HW,
+        "render_fb": (40.0 * R + 8.0 * T + 24.0 * HW) + (76.0 * R + 24.0 * HW),   # forward share + backward share
         "render_bwd": 76.0 * R + 24.0 * HW,
         "preprocess_bwd": 308.0 * P,
     }[kind]
@@ -95,6 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C2", choices=sorted(synthetic.CONFIGS))
     ap.add_argument("--compact", action="store_true", help="secondary compact-splat regime (SURVEY 8d)")
+    ap.add_argument("--two-pass", action="store_true", help="separate forward and backward launch sequences (images kept)")
     ap.add_argument("--unfused", action="store_true", help="torch activations + torch loss around the batched operator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -135,7 +137,7 @@ def main():
         else:
             loss, _, _ = render_loss_fused(head_out, batch.center, batch.world_view, batch.full_proj, batch.camera_center, batch.gt,
                                            batch.bg, batch.fov_deg, H, W, level=level, offset_scale=batch.offset_scale,
-                                           loss_kind=loss_kind)
+                                           loss_kind=loss_kind, single_pass=not a.two_pass, return_images=False)
         loss.backward()
         return loss.detach()
 
@@ -188,10 +190,11 @@ def main():
                 by = algorithmic_bytes(k, P, R_mean, tiles, H * W) * NV
                 kernels[k] = {"avg_ms": avg_ms, "launches": cnt, "algorithmic_GB_per_launch": by / 1e9,
                               "achieved_GBs": by / 1e9 / (avg_ms / 1e3)}
-        hot = {k: v for k, v in kernels.items() if k in ("render_fwd", "render_bwd")}
+        hot = {k: v for k, v in kernels.items() if k in ("render_fwd", "render_bwd", "render_fb")}
         dom = max(hot, key=lambda k: hot[k]["avg_ms"]) if hot else None
         fwd_ms = sum(kernels[k]["avg_ms"] for k in ("preprocess_fwd", "depth_sort", "render_fwd") if k in kernels)
         bwd_ms = sum(kernels[k]["avg_ms"] for k in ("render_bwd", "preprocess_bwd") if k in kernels)
+        fb_ms = sum(kernels[k]["avg_ms"] for k in kernels)
         fwd_bytes = (168.0 * P + 76.0 * R_mean + 8.0 * tiles + 24.0 * H * W) * NV
         bwd_bytes = (308.0 * P + 76.0 * R_mean + 24.0 * H * W) * NV
         out = {
@@ -215,6 +218,11 @@ def main():
                                "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS,
                                "traffic": pmc_traffic(dom, a.config, not a.unfused and not a.compact),
                                "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_GB_per_launch"] * 1e9}
+            out["roofline_rasterizer_fwd_bwd"] = {"achieved": (fwd_bytes + bwd_bytes) / 1e9 / (fb_ms / 1e3), "peak": HBM_PEAK_GBS,
+                                                  "unit": "GB/s", "frac": (fwd_bytes + bwd_bytes) / 1e9 / (fb_ms / 1e3) / HBM_PEAK_GBS,
+                                                  "note": "reference-algorithm bytes fwd (168P+76R+8T+24HW) + bwd (308P+76R+24HW) per view "
+                                                          "over the sum of all rasterizer kernel times of a step"}
+        if dom and "render_fwd" in kernels:
             out["roofline_forward_rasterizer"] = {"achieved": fwd_bytes / 1e9 / (fwd_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                   "frac": fwd_bytes / 1e9 / (fwd_ms / 1e3) / HBM_PEAK_GBS,
                                                   "note": "reference-algorithm bytes 168P+76R+8T+24HW per view over the sum of forward kernel times"}

@@ -164,6 +164,19 @@ int u3d_render_loss_backward(const u3d_raster_desc* desc, const u3d_head_desc* h
                              const float* out_color, const float* dloss, const void* geom, const void* binning,
                              const void* image, void* fused, void* backward_scratch, float* d_head_out, void* stream);
 
+/*
+ * Training form of the fused step: forward AND backward in one launch sequence whose tile kernel blends, evaluates the
+ * loss term, seeds dL/dcolor and walks the same LDS-resident Gaussian batch back to front, so final transmittance, last
+ * contributor and the colour image never round-trip through HBM.
+ *   out_color   [n_views][3][H][W] or NULL (not needed for training)
+ *   loss_out[1] mean loss;  d_head_out [n_items][P][C] = d loss / d head_out  (i.e. for dL/dloss = 1; scale on the host)
+ * Scratch: geom, binning, fused and backward_scratch as above (no image buffer).
+ */
+int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss, const float* bg,
+                         const float* head_out, const float* center, const float* viewmatrix, const float* projmatrix,
+                         const float* campos, const float* gt, float* out_color, int32_t* radii, float* loss_out,
+                         float* d_head_out, void* geom, void* binning, void* fused, void* backward_scratch, void* stream);
+
 /* Frustum test only: replaces `_C.mark_visible` (no caller in the reference tree). present[P] = z_view > 0.2 */
 int u3d_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);
@@ -172,12 +185,13 @@ int u3d_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
  * Measurement hooks (bench.py / profiling only; no reference counterpart).  While enabled, every kernel
  * of the launch sequences is bracketed by a pair of HIP events recorded on the caller's stream, so that
  * per-kernel durations can be read without an external profiler.
- *   kind: 0 preprocess_fwd, 1 depth_sort, 2 render_fwd, 3 render_bwd, 4 preprocess_bwd
+ *   kind: 0 preprocess_fwd, 1 depth_sort, 2 render_fwd, 3 render_bwd (+ partial reduce), 4 preprocess_bwd,
+ *         5 render_fb (fused forward+backward tile kernel + partial reduce)
  * u3d_profile_begin(max_records) allocates the event ring and enables recording (U3D_ERR_INVALID_ARGUMENT
  * if already enabled); u3d_profile_end waits for the recorded events, writes total milliseconds and launch
  * counts per kind into ms[U3D_PROFILE_KINDS] / count[U3D_PROFILE_KINDS], frees the events and disables.
  */
-#define U3D_PROFILE_KINDS 5
+#define U3D_PROFILE_KINDS 6
 int u3d_profile_begin(int32_t max_records);
 int u3d_profile_end(float* ms, int32_t* count);
 

@@ -21,8 +21,8 @@ FLAG_PREFILTERED, FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_EXACT_AA_GRAD = 1, 2, 4, 8
 
 EXPORTS = ("u3d_abi_version", "u3d_error_string", "u3d_scratch_query", "u3d_rasterize_forward",
            "u3d_rasterize_backward", "u3d_mark_visible", "u3d_profile_begin", "u3d_profile_end",
-           "u3d_render_loss_forward", "u3d_render_loss_backward")
-PROFILE_KINDS = ("preprocess_fwd", "depth_sort", "render_fwd", "render_bwd", "preprocess_bwd")
+           "u3d_render_loss_forward", "u3d_render_loss_backward", "u3d_render_loss_step")
+PROFILE_KINDS = ("preprocess_fwd", "depth_sort", "render_fwd", "render_bwd", "preprocess_bwd", "render_fb")
 
 
 class RasterDesc(ctypes.Structure):
@@ -89,6 +89,8 @@ def load() -> ctypes.CDLL:
     lib.u3d_render_loss_forward.argtypes = [ctypes.POINTER(RasterDesc), ctypes.POINTER(HeadDesc), ctypes.POINTER(LossDesc)] + [vp] * 15
     lib.u3d_render_loss_backward.restype = ctypes.c_int
     lib.u3d_render_loss_backward.argtypes = [ctypes.POINTER(RasterDesc), ctypes.POINTER(HeadDesc), ctypes.POINTER(LossDesc)] + [vp] * 17
+    lib.u3d_render_loss_step.restype = ctypes.c_int
+    lib.u3d_render_loss_step.argtypes = [ctypes.POINTER(RasterDesc), ctypes.POINTER(HeadDesc), ctypes.POINTER(LossDesc)] + [vp] * 16
     lib.u3d_profile_begin.restype = ctypes.c_int
     lib.u3d_profile_begin.argtypes = [i32]
     lib.u3d_profile_end.restype = ctypes.c_int

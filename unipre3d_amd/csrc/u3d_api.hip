@@ -307,6 +307,56 @@ int u3d_render_loss_backward(const u3d_raster_desc* desc, const u3d_head_desc* h
   return finish(desc, s);
 }
 
+int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss, const float* bg,
+                         const float* head_out, const float* center, const float* viewmatrix, const float* projmatrix,
+                         const float* campos, const float* gt, float* out_color, int32_t* radii, float* loss_out,
+                         float* d_head_out, void* geom, void* binning, void* fused, void* backward_scratch, void* stream) {
+  int rc = check_fused(desc, head, loss);
+  if (rc != U3D_OK) return rc;
+  const u3d_raster_desc& d = *desc;
+  const int NV = d.n_items * d.views_per_item;
+  if (NV == 0 || d.P == 0) return U3D_ERR_INVALID_ARGUMENT;
+  if (!bg || !head_out || !center || !viewmatrix || !projmatrix || !campos || !gt || !radii || !loss_out || !d_head_out ||
+      !geom || !binning || !fused || !backward_scratch)
+    return U3D_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  U3DBuffers b{};
+  const U3DLayout Lay = u3d_carve(d, geom, binning, nullptr, &b);
+  U3DFused f{};
+  u3d_carve_fused(d, fused, &f);
+  double* acc = (double*)backward_scratch;
+  float* part = (float*)((char*)backward_scratch + Lay.acc_bytes);
+  (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
+  (void)hipMemsetAsync(acc, 0, Lay.acc_bytes, s);
+  (void)hipMemsetAsync(f.qdot, 0, sizeof(float) * 4 * d.n_items, s);
+  if (head->mode == 1) u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, s);
+  const U3DSource src = head_source(d, *head, head_out, center, f.qnorm);
+  {
+    ProfScope ps(0, s);
+    u3d_launch_preprocess_fwd(d, b, src, viewmatrix, projmatrix, campos, radii, s);
+  }
+  {
+    ProfScope ps(1, s);
+    u3d_launch_depth_sort(d, b, radii, s);
+  }
+  const int T = ((d.image_width + U3D_TILE - 1) / U3D_TILE) * ((d.image_height + U3D_TILE - 1) / U3D_TILE);
+  const U3DLoss L = make_loss(d, *loss, gt, f.partial, nullptr);
+  {
+    ProfScope ps(5, s);
+    u3d_launch_render_fb(d, b, bg, out_color, L, acc, part, s);
+  }
+  u3d_launch_loss_reduce(NV * T, f.partial, L.inv_count, loss_out, s);
+  U3DGradSink sink{};
+  sink.means = d_head_out; sink.opac = d_head_out + 3; sink.scales = d_head_out + 4; sink.rots = d_head_out + 7;
+  sink.shs = d_head_out + 11; sink.colors = nullptr; sink.cov = nullptr; sink.means2D = nullptr; sink.qdot = f.qdot;
+  {
+    ProfScope ps(4, s);
+    u3d_launch_preprocess_bwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, sink, s);
+  }
+  if (head->mode == 1) u3d_launch_quat_fixup(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, f.qdot, d_head_out + 7, s);
+  return finish(desc, s);
+}
+
 int u3d_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream) {
   (void)projmatrix;

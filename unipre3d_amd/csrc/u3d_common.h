@@ -164,6 +164,8 @@ void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
 void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, const float* dL_dcolor,
                            const float* dL_dinvdepth, const float* out_color, const U3DLoss& loss, double* acc,
                            float* part, hipStream_t s);
+void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,
+                          const U3DLoss& loss, double* acc, float* part, hipStream_t s);
 void u3d_launch_loss_reduce(int n, const float* partial, float inv_count, float* loss_out, hipStream_t s);
 
 #ifdef __HIPCC__

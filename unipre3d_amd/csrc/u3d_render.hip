@@ -663,6 +663,259 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_bwd_wave_kerne
   if (lane == 0) reinterpret_cast<uint32_t*>(pt)[U3D_NACC * U3D_WAVE] = cnt;
 }
 
+// ---- forward + backward in ONE kernel (training step of the fused render-loss path) -----------------
+// The render loss needs nothing but the pixel's own colour and gt, so a tile can blend front to back, evaluate its
+// loss term and seed dL/dcolor, and immediately walk the same LDS-resident batch back to front: final_T, n_contrib and
+// the colour image never round-trip through HBM, the Gaussian batch is staged once, and one prologue disappears.
+// dL/dloss is taken as 1 (the result is linear in it; the host scales the stored gradient).  Same arithmetic, same
+// order as render_fwd_wave_kernel followed by render_bwd_wave_kernel<false>.
+__global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel(
+    int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t nblocks, size_t NG,
+    const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis,
+    const float2* __restrict__ xy, const float4* __restrict__ conic_op, const float4* __restrict__ rgbd,
+    const float* __restrict__ bg, float* __restrict__ out_color, double* __restrict__ acc, float* __restrict__ part,
+    U3DLoss loss) {
+  constexpr int NK = U3D_NACC - 1;
+  __shared__ float4 sA[BWD_WAVES][U3D_WAVE];   // x, y, a, b
+  __shared__ float4 sB[BWD_WAVES][U3D_WAVE];   // c, opacity, 1/depth, pos (bits)
+  __shared__ float4 sC[BWD_WAVES][U3D_WAVE];   // r, g, b, id (bits)
+  __shared__ float sAcc[BWD_WAVES][U3D_NACC][U3D_WAVE];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t lid = u3d_xcd_remap(blockIdx.x, nblocks) * (uint32_t)BWD_WAVES + (uint32_t)wave;
+  if (lid >= ntiles_total) return;
+  const int view = (int)(lid / T);
+  const int tile = (int)lid - view * T;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int px = tx * U3D_TILE + (lane & 15);
+  const int py0 = ty * U3D_TILE + (lane >> 4);
+  const float pxf = (float)px;
+  const size_t vbase = (size_t)view * P;
+  const size_t npix = (size_t)H * W;
+  const uint32_t nv = n_vis[view];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) sAcc[wave][k][lane] = 0.f;
+
+  // stage sorted entries [b*64, b*64+64) limited to `limit`; returns the hit ballot
+  auto stage = [&](int b, uint32_t limit) -> unsigned long long {
+    const uint32_t s = (uint32_t)b * U3D_WAVE + (uint32_t)lane;
+    bool hit = false;
+    if (s < limit) hit = rect_hits(sorted_rect[vbase + s], tx, ty);
+    const unsigned long long bal = __ballot(hit);
+    if (hit) {
+      const uint32_t o = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      const uint32_t id = sorted_id[vbase + s];
+      const size_t g = vbase + id;
+      const float2 m = xy[g];
+      const float4 co = conic_op[g];
+      const float4 cd = rgbd[g];
+      sA[wave][o] = make_float4(m.x, m.y, co.x, co.y);
+      sB[wave][o] = make_float4(co.z, co.w, 1.0f / cd.w, __uint_as_float(s + 1u));
+      sC[wave][o] = make_float4(cd.x, cd.y, cd.z, __uint_as_float(id));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return bal;
+  };
+
+  float pyf[4], Tr[4], C0[4], C1[4], C2[4];
+  uint32_t last[4];
+  bool done[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int py = py0 + 4 * k;
+    pyf[k] = (float)py;
+    Tr[k] = 1.f; C0[k] = C1[k] = C2[k] = 0.f; last[k] = 0u;
+    done[k] = !(px < W && py < H);
+  }
+  bool all_done = done[0] && done[1] && done[2] && done[3];
+
+  // ---------------- forward ----------------
+  int staged = -1;
+  unsigned long long staged_bal = 0ull;
+  const int nbf = (int)((nv + U3D_WAVE - 1) / U3D_WAVE);
+  for (int b = 0; b < nbf; ++b) {
+    if (__ballot(!all_done) == 0ull) break;
+    const unsigned long long bal = stage(b, nv);
+    staged = b; staged_bal = bal;
+    const int total = __popcll(bal);
+    for (int j = 0; j < total; ++j) {
+      const float4 A = sA[wave][j];
+      const float4 B = sB[wave][j];
+      const float4 Cc = sC[wave][j];
+      const float dx = A.x - pxf;
+      const float adx = (-0.5f * LOG2E * A.z) * dx, bdx = (-LOG2E * A.w) * dx, cl = -0.5f * LOG2E * B.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dy = A.y - pyf[k];
+        const float pw = fmaf(adx, dx, fmaf(cl * dy, dy, bdx * dy));
+        const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(pw));
+        const bool ok = !done[k] && pw <= 0.f && alpha >= ALPHA_MIN;
+        const float test_T = Tr[k] * (1.f - alpha);
+        const bool stop = ok && test_T < T_STOP;
+        done[k] = done[k] || stop;
+        if (ok && !stop) {
+          const float w = alpha * Tr[k];
+          C0[k] = fmaf(Cc.x, w, C0[k]);
+          C1[k] = fmaf(Cc.y, w, C1[k]);
+          C2[k] = fmaf(Cc.z, w, C2[k]);
+          Tr[k] = test_T;
+          last[k] = __float_as_uint(B.w);
+        }
+      }
+      all_done = done[0] && done[1] && done[2] && done[3];
+      if (__ballot(!all_done) == 0ull) break;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---------------- loss term, dL/dcolor seed ----------------
+  float T_final[4], dp0[4], dp1[4], dp2[4], bg_dot[4];
+  float e = 0.f;
+  uint32_t wmax = 0;
+  const float sc = loss.inv_count;   // dL/dloss == 1
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int py = py0 + 4 * k;
+    T_final[k] = 0.f; dp0[k] = dp1[k] = dp2[k] = 0.f;
+    if (px < W && py < H) {
+      const size_t pid = (size_t)py * W + px;
+      T_final[k] = Tr[k];
+      const float o0 = fmaf(Tr[k], bg[0], C0[k]), o1 = fmaf(Tr[k], bg[1], C1[k]), o2 = fmaf(Tr[k], bg[2], C2[k]);
+      if (out_color) {
+        float* oc = out_color + (size_t)view * 3 * npix + pid;
+        oc[0] = o0; oc[npix] = o1; oc[2 * npix] = o2;
+      }
+      const float* gp = loss.gt + (size_t)view * 3 * npix + pid;
+      const float g0 = gp[0], g1 = gp[npix], g2 = gp[2 * npix];
+      const float d0 = o0 - g0, d1 = o1 - g1, d2 = o2 - g2;
+      e += loss_pixel(loss, bg, g0, g1, g2, d0, d1, d2);
+      if (loss.kind == 3) {
+        dp0[k] = sc * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
+        dp1[k] = sc * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+        dp2[k] = sc * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
+      } else {
+        const float w2 = 2.f * sc * focal_weight(loss, bg, g0, g1, g2);
+        dp0[k] = w2 * d0; dp1[k] = w2 * d1; dp2[k] = w2 * d2;
+      }
+    } else {
+      last[k] = 0u;
+    }
+    bg_dot[k] = bg[0] * dp0[k] + bg[1] * dp1[k] + bg[2] * dp2[k];
+    wmax = max(wmax, last[k]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    e += __shfl_xor(e, o);
+    wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o));
+  }
+  if (lane == 0) loss.partial[lid] = e;
+
+  // ---------------- backward ----------------
+  float ar0[4], ar1[4], ar2[4], lc0[4], lc1[4], lc2[4], last_alpha[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    Tr[k] = T_final[k];
+    ar0[k] = ar1[k] = ar2[k] = lc0[k] = lc1[k] = lc2[k] = last_alpha[k] = 0.f;
+  }
+  const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+  const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
+  for (int b = nb - 1; b >= 0; --b) {
+    unsigned long long bal = staged_bal;
+    if (b != staged) { bal = stage(b, wmax); staged = b; staged_bal = bal; }
+    // entries of this batch with pos <= wmax (the compaction keeps positions ascending)
+    const uint32_t lim = wmax - (uint32_t)b * U3D_WAVE;
+    const int total = lim >= U3D_WAVE ? __popcll(bal) : __popcll(bal & ((1ull << lim) - 1ull));
+    for (int j = total - 1; j >= 0; --j) {
+      const float4 A = sA[wave][j];
+      const float4 B = sB[wave][j];
+      const float4 Cc = sC[wave][j];
+      const uint32_t pos = __float_as_uint(B.w);
+      const float dx = A.x - pxf;
+      const float adx = (-0.5f * LOG2E * A.z) * dx, bdx = (-LOG2E * A.w) * dx, cl = -0.5f * LOG2E * B.x;
+      float m0 = 0.f, mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dy = A.y - pyf[k];
+        const float pw = fmaf(adx, dx, fmaf(cl * dy, dy, bdx * dy));
+        const float G = __builtin_amdgcn_exp2f(pw);
+        const float alpha = fminf(0.99f, B.y * G);
+        const bool ok = pos <= last[k] && pw <= 0.f && alpha >= ALPHA_MIN;
+        if (ok) {
+          any = true;
+          const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
+          Tr[k] = Tr[k] * rc;
+          const float w = alpha * Tr[k];
+          const float la = last_alpha[k];
+          ar0[k] = la * lc0[k] + (1.f - la) * ar0[k]; lc0[k] = Cc.x;
+          ar1[k] = la * lc1[k] + (1.f - la) * ar1[k]; lc1[k] = Cc.y;
+          ar2[k] = la * lc2[k] + (1.f - la) * ar2[k]; lc2[k] = Cc.z;
+          float dL_dalpha = (Cc.x - ar0[k]) * dp0[k] + (Cc.y - ar1[k]) * dp1[k] + (Cc.z - ar2[k]) * dp2[k];
+          g_r = fmaf(w, dp0[k], g_r); g_g = fmaf(w, dp1[k], g_g); g_b = fmaf(w, dp2[k], g_b);
+          dL_dalpha *= Tr[k];
+          last_alpha[k] = alpha;
+          dL_dalpha += (-T_final[k] * rc) * bg_dot[k];
+          const float q = B.y * dL_dalpha * G;
+          const float qdx = q * dx, qdy = q * dy;
+          m0 += q; mx += qdx; my += qdy;
+          mxx = fmaf(qdx, dx, mxx); mxy = fmaf(qdx, dy, mxy); myy = fmaf(qdy, dy, myy);
+        }
+      }
+      if (__ballot(any) == 0ull) continue;
+#define U3D_DPP9(CTRL)                                                                                              \
+  asm volatile("s_nop 1\n\t"                                                                                        \
+               "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\t"                        \
+               "v_add_f32_dpp %2, %2, %2 " CTRL "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\t"                        \
+               "v_add_f32_dpp %4, %4, %4 " CTRL "\n\tv_add_f32_dpp %5, %5, %5 " CTRL "\n\t"                        \
+               "v_add_f32_dpp %6, %6, %6 " CTRL "\n\tv_add_f32_dpp %7, %7, %7 " CTRL "\n\t"                        \
+               "v_add_f32_dpp %8, %8, %8 " CTRL "\n\ts_nop 1"                                                       \
+               : "+v"(m0), "+v"(mx), "+v"(my), "+v"(mxx), "+v"(mxy), "+v"(myy), "+v"(g_r), "+v"(g_g), "+v"(g_b))
+      U3D_DPP9("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+      U3D_DPP9("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+      U3D_DPP9("row_half_mirror row_mask:0xf bank_mask:0xf");
+      U3D_DPP9("row_mirror row_mask:0xf bank_mask:0xf");
+      U3D_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf");
+      U3D_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef U3D_DPP9
+      if (lane == 63) {
+        const int slot = b == 0 ? (int)pos - 1 : j;
+        sAcc[wave][0][slot] = -ddelx_dx * (A.z * mx + A.w * my);
+        sAcc[wave][1][slot] = -ddely_dy * (B.x * my + A.w * mx);
+        sAcc[wave][2][slot] = -0.5f * mxx;
+        sAcc[wave][3][slot] = -0.5f * mxy;
+        sAcc[wave][4][slot] = -0.5f * myy;
+        sAcc[wave][5][slot] = m0 / B.y;
+        sAcc[wave][6][slot] = g_r; sAcc[wave][7][slot] = g_g; sAcc[wave][8][slot] = g_b;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (b > 0) {
+      if (lane < total) {
+        const size_t g = vbase + __float_as_uint(sC[wave][lane].w);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const float v = sAcc[wave][k][lane];
+          if (v != 0.f) unsafeAtomicAdd(&acc[(size_t)k * NG + g], (double)v);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NK; ++k) sAcc[wave][k][lane] = 0.f;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  float* pt = part + (size_t)lid * BWD_PART_STRIDE;
+  const uint32_t cnt = min(wmax, (uint32_t)U3D_WAVE);
+  if ((uint32_t)lane < cnt) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) pt[k * U3D_WAVE + lane] = sAcc[wave][k][lane];
+  }
+  if (lane == 0) reinterpret_cast<uint32_t*>(pt)[U3D_NACC * U3D_WAVE] = cnt;
+}
+
 // acc[k][view*P + sorted_id[sp]] += sum over a slice of the view's tiles (ascending) of part[tile][k][sp], in f64;
 // the BWD_REDUCE_SPLIT slices of a view meet in an f64 atomic (order-insensitive at fp32 output precision).
 __global__ __launch_bounds__(U3D_NACC * U3D_WAVE) void bwd_reduce_kernel(int P, int T, int NK, size_t NG,
@@ -734,6 +987,21 @@ void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   hipLaunchKernelGGL(render_fwd_kernel, dim3(nblocks), dim3(U3D_BLOCK), 0, s, d.P, d.image_height, d.image_width,
                      tiles_x, T, nblocks, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
                      out_invdepth, b.final_T, b.n_contrib, loss);
+}
+
+void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,
+                          const U3DLoss& loss, double* acc, float* part, hipStream_t s) {
+  const int tiles_x = (d.image_width + U3D_TILE - 1) / U3D_TILE, tiles_y = (d.image_height + U3D_TILE - 1) / U3D_TILE;
+  const int T = tiles_x * tiles_y;
+  const uint32_t nblocks = (uint32_t)(d.n_items * d.views_per_item * T);
+  const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
+  if (nblocks == 0 || NG == 0) return;
+  const uint32_t nwg = (nblocks + BWD_WAVES - 1u) / BWD_WAVES;
+  hipLaunchKernelGGL(render_fb_wave_kernel, dim3(nwg), dim3(BWD_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
+                     tiles_x, T, nblocks, nwg, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
+                     acc, part, loss);
+  hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, BWD_REDUCE_SPLIT), dim3(U3D_NACC * U3D_WAVE), 0, s, d.P,
+                     T, U3D_NACC - 1, NG, b.sorted_id, part, acc);
 }
 
 void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, const float* dL_dcolor,

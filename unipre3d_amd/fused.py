@@ -69,13 +69,63 @@ class _RenderLossFn(torch.autograd.Function):
         return (d_head,) + (None,) * 17
 
 
+class _RenderLossStepFn(torch.autograd.Function):
+    """Training form: ONE launch sequence computes the loss and d loss / d head_out (u3d_render_loss_step); autograd's
+    backward only scales the stored gradient by dL/dloss."""
+
+    @staticmethod
+    def forward(ctx, head_out, center, viewmatrix, projmatrix, campos, gt, bg, H, W, tanfov, mode, offset_scale, sh_degree,
+                loss_kind, non_bg_rate, bg_rate, scale_modifier, flags, want_color):
+        lib = _lib.load()
+        dev = head_out.device
+        if dev.type != "cuda":
+            raise RuntimeError("the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback")
+        B, P, C = head_out.shape
+        NV = viewmatrix.shape[0]
+        K = (sh_degree + 1) ** 2
+        if C != 11 + 3 * K:
+            raise ValueError(f"head output has {C} channels, expected {11 + 3 * K} for SH degree {sh_degree}")
+        plan = _Plan(B, NV // B, P, H, W, tanfov, tanfov, scale_modifier, sh_degree, K, flags)
+        hd = _lib.HeadDesc(mode, C, offset_scale)
+        ld = _lib.LossDesc(_lib.LOSS_KINDS[loss_kind], non_bg_rate, bg_rate)
+        color = torch.empty((NV, 3, H, W), dtype=torch.float32, device=dev) if want_color else None
+        radii = torch.empty((NV, P), dtype=torch.int32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        d_head = torch.empty_like(head_out)
+        u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+        geom, binning, fused, scratch = u8(plan.sizes.geom_bytes), u8(plan.sizes.binning_bytes), u8(plan.sizes.fused_bytes), \
+            u8(plan.sizes.backward_bytes)
+        p = _lib.ptr
+        rc = lib.u3d_render_loss_step(ctypes.byref(plan.desc), ctypes.byref(hd), ctypes.byref(ld), p(bg), p(head_out), p(center),
+                                      p(viewmatrix), p(projmatrix), p(campos), p(gt), p(color), p(radii), p(loss), p(d_head),
+                                      p(geom), p(binning), p(fused), p(scratch), _stream_ptr())
+        _lib.check(rc, "u3d_render_loss_step")
+        ctx.save_for_backward(d_head)
+        ctx.set_materialize_grads(False)
+        if color is None:
+            color = torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(color, radii)
+        return loss, color, radii
+
+    @staticmethod
+    def backward(ctx, grad_loss, _gc, _gr):
+        (d_head,) = ctx.saved_tensors
+        if grad_loss is None:
+            return (torch.zeros_like(d_head),) + (None,) * 18
+        return (d_head * grad_loss,) + (None,) * 18
+
+
 def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: torch.Tensor, full_proj: torch.Tensor,
                       camera_center: torch.Tensor, gt: torch.Tensor, bg: torch.Tensor, fov_deg: float, H: int, W: int,
                       level: str = "object", offset_scale: float = 1.0, max_sh_degree: int = 1, loss_kind: str = "focal_l2",
                       non_bg_color_loss_rate: float = 4.0, bg_color_loss_rate: float = 1.0, input_images: int = 0,
-                      scaling_modifier: float = 1.0, antialiasing: bool = True, debug: bool = False):
+                      scaling_modifier: float = 1.0, antialiasing: bool = True, debug: bool = False,
+                      single_pass: bool = True, return_images: bool = True):
     """head_out (B,P,C) point-major raw head output (C = 23 at SH degree 1), center (B,P,3), cameras (B,Vtot,...),
-    gt (B,Vtot,3,H,W).  Returns (loss scalar, rendered (B*V',3,H,W) detached, radii (B*V',P))."""
+    gt (B,Vtot,3,H,W).  Returns (loss scalar, rendered (B*V',3,H,W) detached, radii (B*V',P)).
+    single_pass (default): when a gradient is wanted, forward and backward run as ONE launch sequence
+    (u3d_render_loss_step) and autograd's backward only scales the stored gradient; return_images=False additionally
+    skips writing the rendered images (the training loop only needs the loss)."""
     dev = head_out.device
     B = head_out.shape[0]
     wv, fp, cc = world_view[:, input_images:], full_proj[:, input_images:], camera_center[:, input_images:]
@@ -83,6 +133,12 @@ def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: 
     t = math.tan(fov_deg * math.pi / 360)
     flags = (_lib.FLAG_ANTIALIASING if antialiasing else 0) | (_lib.FLAG_DEBUG if debug else 0)
     f = lambda x: _f32c(x, dev)
+    if single_pass and head_out.requires_grad and torch.is_grad_enabled():
+        return _RenderLossStepFn.apply(f(head_out), f(center), f(wv).reshape(NV, 16), f(fp).reshape(NV, 16), f(cc).reshape(NV, 3),
+                                       f(gt[:, input_images:]).reshape(NV, 3, H, W), f(bg).reshape(3), int(H), int(W), float(t),
+                                       1 if level == "object" else 2, float(offset_scale), int(max_sh_degree), loss_kind,
+                                       float(non_bg_color_loss_rate), float(bg_color_loss_rate), float(scaling_modifier), flags,
+                                       bool(return_images))
     return _RenderLossFn.apply(f(head_out), f(center), f(wv).reshape(NV, 16), f(fp).reshape(NV, 16), f(cc).reshape(NV, 3),
                                f(gt[:, input_images:]).reshape(NV, 3, H, W), f(bg).reshape(3), int(H), int(W), float(t),
                                1 if level == "object" else 2, float(offset_scale), int(max_sh_degree), loss_kind,

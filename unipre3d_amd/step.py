@@ -46,7 +46,7 @@ def train_step(model: torch.nn.Module, feats: torch.Tensor, batch: SyntheticBatc
         head_out = model(feats, point_major=True)
         loss, _, _ = render_loss_fused(head_out, batch.center, batch.world_view, batch.full_proj, batch.camera_center, batch.gt,
                                        batch.bg, batch.fov_deg, H, W, level=batch.level, offset_scale=batch.offset_scale,
-                                       loss_kind=loss_kind, input_images=input_images)
+                                       loss_kind=loss_kind, input_images=input_images, return_images=False)
     else:
         raw = model(feats)
         loss, _ = render_loss_forward(raw, batch, H, W, input_images, loss_kind, render_fn)
