@@ -42,16 +42,18 @@ def algorithmic_bytes(kind: str, P: int, R: float, T: int, HW: int) -> float:
     }[kind]
 
 
-def pmc_traffic(kernel: str, config: str, fused: bool):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01/pmc_traffic_C2.json: separate FETCH_SIZE /
-    WRITE_SIZE runs of this very command, FETCH_SIZE doubled per the gfx950 calibration).  None when the run does not
-    match the profiled workload."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_C2.json")
-    if config != "C2" or not fused or not os.path.exists(path):
+def pmc_traffic(kernel: str, config: str, default_path: bool):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01/pmc_traffic_C2_single_pass.json: separate
+    FETCH_SIZE / WRITE_SIZE runs of this very command, FETCH_SIZE doubled per the gfx950 calibration).  None when the
+    run does not match the profiled workload."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_C2_single_pass.json")
+    if config != "C2" or not default_path or not os.path.exists(path):
         return None
     per = json.load(open(path))["per_launch"]
-    key = {"render_fwd": "render_fwd_kernel", "render_bwd": "render_bwd_wave_kernel"}.get(kernel)
-    return per[key]["hbm_bytes_corrected"] if key in per else None
+    key = {"render_fb": "render_fb_wave_kernel"}.get(kernel)
+    if key not in per:
+        return None
+    return per[key]["hbm_bytes_corrected"] + per.get("bwd_reduce_kernel", {}).get("hbm_bytes_corrected", 0.0)
 
 
 def cpu_baseline(batch, H, W, min_seconds=10.0, max_views=8):
@@ -216,7 +218,7 @@ def main():
         if dom:
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS,
-                               "traffic": pmc_traffic(dom, a.config, not a.unfused and not a.compact),
+                               "traffic": pmc_traffic(dom, a.config, not (a.unfused or a.compact or a.two_pass)),
                                "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_GB_per_launch"] * 1e9}
             out["roofline_rasterizer_fwd_bwd"] = {"achieved": (fwd_bytes + bwd_bytes) / 1e9 / (fb_ms / 1e3), "peak": HBM_PEAK_GBS,
                                                   "unit": "GB/s", "frac": (fwd_bytes + bwd_bytes) / 1e9 / (fb_ms / 1e3) / HBM_PEAK_GBS,

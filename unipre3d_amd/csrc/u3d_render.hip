@@ -927,19 +927,30 @@ __global__ __launch_bounds__(U3D_NACC * U3D_WAVE) void bwd_reduce_kernel(int P, 
   const int per = (T + BWD_REDUCE_SPLIT - 1) / BWD_REDUCE_SPLIT;
   const int t0 = blockIdx.y * per, t1 = min(T, t0 + per);
   const float* base = part + (size_t)view * T * BWD_PART_STRIDE;
+  // loads are unconditional (rows a tile did not write hold stale bytes, discarded by the select) so that a whole group
+  // of tiles is in flight at once; accumulation order stays ascending in t within each of the two chains
   double a0 = 0.0, a1 = 0.0;
   int t = t0;
-  for (; t + 1 < t1; t += 2) {
-    const float* p0 = base + (size_t)t * BWD_PART_STRIDE;
-    const float* p1 = p0 + BWD_PART_STRIDE;
-    const uint32_t c0 = reinterpret_cast<const uint32_t*>(p0)[U3D_NACC * U3D_WAVE];
-    const uint32_t c1 = reinterpret_cast<const uint32_t*>(p1)[U3D_NACC * U3D_WAVE];
-    if ((uint32_t)sp < c0) a0 += (double)p0[k * U3D_WAVE + sp];
-    if ((uint32_t)sp < c1) a1 += (double)p1[k * U3D_WAVE + sp];
+  for (; t + 7 < t1; t += 8) {
+    float v[8];
+    uint32_t c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* pu = base + (size_t)(t + u) * BWD_PART_STRIDE;
+      c[u] = reinterpret_cast<const uint32_t*>(pu)[U3D_NACC * U3D_WAVE];
+      v[u] = pu[k * U3D_WAVE + sp];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      a0 += (uint32_t)sp < c[u] ? (double)v[u] : 0.0;
+      a1 += (uint32_t)sp < c[u + 1] ? (double)v[u + 1] : 0.0;
+    }
   }
-  if (t < t1) {
+  for (; t < t1; ++t) {
     const float* p0 = base + (size_t)t * BWD_PART_STRIDE;
-    if ((uint32_t)sp < reinterpret_cast<const uint32_t*>(p0)[U3D_NACC * U3D_WAVE]) a0 += (double)p0[k * U3D_WAVE + sp];
+    const uint32_t c0 = reinterpret_cast<const uint32_t*>(p0)[U3D_NACC * U3D_WAVE];
+    const float v0 = p0[k * U3D_WAVE + sp];
+    a0 += (uint32_t)sp < c0 ? (double)v0 : 0.0;
   }
   const double a = a0 + a1;
   if (a != 0.0) unsafeAtomicAdd(&acc[(size_t)k * NG + (size_t)view * P + sorted_id[(size_t)view * P + sp]], a);
