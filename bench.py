@@ -208,7 +208,7 @@ def main():
                        "global_batch": B * world, "views_per_step": NV * world, "parallelism": f"dp{world}",
                        "loss": loss_kind, "num_rendered_per_view": R_mean,
                        "path": "unfused (torch activations/loss)" if a.unfused else "fused head-activation + render + loss (HIP)"},
-            "render_loss_step_ms": {"rasterizer_fwd_kernels": fwd_ms, "rasterizer_bwd_kernels": bwd_ms, "kernels": kernels},
+            "render_loss_step_ms": {"rasterizer_kernels_total": fb_ms, "kernels": kernels},
             "train_step_with_head": {"value": world * NV * a.steps / elapsed_train, "unit": "views/s",
                                      "ms_per_step": 1e3 * elapsed_train / a.steps,
                                      "what": "Gaussian head MLP fwd/bwd + hot path + " + ("DDP all-reduce (RCCL) + " if world > 1 else "")
