@@ -129,6 +129,8 @@ def main():
 
     from unipre3d_amd.fused import render_loss_fused
     head_out = model.module(feats, point_major=True).detach() if world > 1 else model(feats, point_major=True).detach()
+    if a.compact:                                              # secondary regime: scale = exp(N(-4, 0.5))
+        head_out[..., 4:7] = -4.0 + 0.5 * head_out[..., 4:7]
     head_out = head_out.contiguous().requires_grad_(True)      # (B,P,23): the raw head output the hot path starts from
 
     def hot_step():
