@@ -1,0 +1,62 @@
+"""HIP point operators against the oracle: indices bit-exact, gathered values bit-exact, scatter-add
+gradients to fp32 summation order."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pointops as po
+from test_pointops_oracle import _cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,N,M,grid", [(4, 1024, 128, False), (2, 1000, 100, True), (3, 2048, 512, False), (2, 5000, 64, True),
+                                        (1, 9000, 32, False), (2, 17, 17, False), (1, 1, 1, False)])
+def test_fps_bit_exact(B, N, M, grid):
+    from unipre3d_amd import pointops
+    xyz = _cloud(B, N, seed=N, grid=grid)
+    got = pointops.furthest_point_sample(torch.from_numpy(xyz).cuda(), M).cpu().numpy()
+    assert got.dtype == np.int32 and np.array_equal(got, po.furthest_point_sampling(xyz, M))
+
+
+@pytest.mark.parametrize("B,N,M,r,K", [(4, 1024, 128, 0.1, 32), (2, 1000, 77, 0.3, 16), (1, 70, 5, 5.0, 64), (2, 300, 10, 1e-4, 8)])
+def test_ball_query_bit_exact(B, N, M, r, K):
+    from unipre3d_amd import pointops
+    xyz = (_cloud(B, N, seed=7) * 0.3).astype(np.float32)
+    new = xyz[:, :M].copy() + (0.0 if r > 1e-3 else 10.0)          # last case: no neighbour at all -> zeros
+    got = pointops.ball_query(r, K, torch.from_numpy(xyz).cuda(), torch.from_numpy(new).cuda()).cpu().numpy()
+    assert np.array_equal(got, po.ball_query(r, K, xyz, new))
+
+
+def test_group_gather_forward_backward():
+    from unipre3d_amd import pointops
+    rng = np.random.RandomState(2)
+    pts = rng.randn(3, 16, 400).astype(np.float32)
+    idx = rng.randint(0, 400, (3, 50, 8)).astype(np.int32)
+    f = torch.from_numpy(pts).cuda().requires_grad_(True)
+    out = pointops.grouping_operation(f, torch.from_numpy(idx).cuda())
+    assert np.array_equal(out.detach().cpu().numpy(), po.group_points(pts, idx))
+    go = rng.randn(*out.shape).astype(np.float32)
+    out.backward(torch.from_numpy(go).cuda())
+    assert np.allclose(f.grad.cpu().numpy(), po.group_points_grad(go, idx, 400), rtol=1e-5, atol=1e-5)
+    f.grad = None
+    gi = np.ascontiguousarray(idx[:, :, 0])
+    out = pointops.gather_operation(f, torch.from_numpy(gi).cuda())
+    assert np.array_equal(out.detach().cpu().numpy(), po.gather_points(pts, gi))
+    out.backward(torch.from_numpy(np.ascontiguousarray(go[:, :, :, 0])).cuda())
+    assert np.allclose(f.grad.cpu().numpy(), po.gather_points_grad(go[:, :, :, 0], gi, 400), rtol=1e-5, atol=1e-5)
+
+
+def test_transformer_tokenizer_pipeline():
+    """The grouping front end of the reference's transformer backbone (openpoints/models/backbone/transformer.py:290-327):
+    FPS(128) -> ball query(r=0.1, k=32) -> group, on a ShapeNet-sized cloud."""
+    from unipre3d_amd import pointops
+    xyz = (_cloud(8, 1024, seed=3) * 0.2).astype(np.float32)
+    x = torch.from_numpy(xyz).cuda()
+    centers = pointops.fps(x, 128)
+    cidx = po.furthest_point_sampling(xyz, 128)
+    assert np.array_equal(centers.cpu().numpy(), np.take_along_axis(xyz, cidx[..., None].astype(np.int64), 1))
+    gx, gf = pointops.QueryAndGroup(0.1, 32)(centers.contiguous(), x, x.transpose(1, 2).contiguous())
+    assert gx.shape == (8, 3, 128, 32) and gf.shape == (8, 3, 128, 32)
+    idx = po.ball_query(0.1, 32, xyz, centers.cpu().numpy())
+    assert np.array_equal(gf.cpu().numpy(), po.group_points(xyz.transpose(0, 2, 1).copy(), idx))

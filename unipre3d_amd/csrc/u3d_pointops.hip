@@ -1,0 +1,254 @@
+// Point sampling / grouping operators for gfx950; semantics: oracle/pointops_oracle.c, which restates
+// openpoints/cpp/pointnet2_batch/src/{sampling,ball_query,group_points}_gpu.cu.
+//
+//  * furthest point sampling: one 1024-thread workgroup per cloud, coordinates staged once in LDS, per-point minimum
+//    distances kept in REGISTERS (the reference round-trips a (B,N) temp array through global memory every iteration),
+//    arg-max as a single u64 max over (distance bits << 32 | inverted tie key): DPP/shuffle within the wave, 16 wave
+//    results through double-buffered LDS => ONE barrier per selected point.  The tie key reproduces the order in which the
+//    reference's shared-memory tree resolves equal distances for ITS block size, so the selection is bit-identical.
+//  * ball query: one WAVE per query (the reference: one thread per query scanning all N points serially): 64 candidates
+//    per step, ballot + popcount prefix keeps index order, early exit at nsample.
+//  * group / gather (+grad): one thread per output element, coalesced on the output side.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "unipre3d_pointops.h"
+
+namespace {
+
+__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = bx - ax, dy = by - ay, dz = bz - az;
+  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long w = __shfl_xor(v, o);
+    v = w > v ? w : v;
+  }
+  return v;
+}
+
+constexpr int FPS_THREADS = 1024;
+constexpr int FPS_WAVES = FPS_THREADS / 64;
+
+// tie key of point k for the reference's block size bs = 2^lg: equal distances are won by the smaller
+// (bit-reversed (k mod bs), k div bs)  [per-thread strided scan keeps the first maximum; the tree keeps the lower slot]
+__device__ __forceinline__ uint32_t fps_tie_key(uint32_t k, int lg, uint32_t bs, uint32_t qn) {
+  const uint32_t r = lg ? (__brev(k & (bs - 1)) >> (32 - lg)) : 0u;
+  return r * qn + (k >> lg);
+}
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int lg, const float* __restrict__ dataset,
+                                                          int32_t* __restrict__ idxs) {
+  extern __shared__ __attribute__((aligned(16))) float s_xyz[];   // [n][3]
+  __shared__ unsigned long long s_key[2][FPS_WAVES];
+  const int bi = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* ds = dataset + (size_t)bi * n * 3;
+  int32_t* out = idxs + (size_t)bi * m;
+  for (int i = tid; i < n * 3; i += FPS_THREADS) s_xyz[i] = ds[i];
+  __syncthreads();
+  const uint32_t bs = 1u << lg, qn = (uint32_t)((n + (int)bs - 1) >> lg) + 1u;
+  float x[PPT], y[PPT], z[PPT], t[PPT];
+  uint32_t inv_tk[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = tid + i * FPS_THREADS;
+    const bool v = k < n;
+    x[i] = v ? s_xyz[k * 3] : 0.f; y[i] = v ? s_xyz[k * 3 + 1] : 0.f; z[i] = v ? s_xyz[k * 3 + 2] : 0.f;
+    t[i] = 1e10f;
+    inv_tk[i] = v ? 0xFFFFFFFFu - fps_tie_key((uint32_t)k, lg, bs, qn) : 0u;
+  }
+  int old = 0;
+  if (tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float ox = s_xyz[old * 3], oy = s_xyz[old * 3 + 1], oz = s_xyz[old * 3 + 2];
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int k = tid + i * FPS_THREADS;
+      if (k < n) {
+        const float d = dist2(ox, oy, oz, x[i], y[i], z[i]);
+        t[i] = fminf(d, t[i]);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(t[i]) << 32) | inv_tk[i];
+        best = key > best ? key : best;
+      }
+    }
+    best = wave_max_u64(best);
+    if (lane == 0) s_key[j & 1][wave] = best;
+    __syncthreads();
+    unsigned long long w = s_key[j & 1][lane & (FPS_WAVES - 1)];
+#pragma unroll
+    for (int o = FPS_WAVES / 2; o > 0; o >>= 1) {
+      const unsigned long long u = __shfl_xor(w, o);
+      w = u > w ? u : w;
+    }
+    const uint32_t tk = 0xFFFFFFFFu - (uint32_t)w;
+    const uint32_t r = tk / qn, q = tk - r * qn;
+    old = (int)((q << lg) + (lg ? (__brev(r) >> (32 - lg)) : 0u));
+    if (tid == 0) out[j] = old;
+  }
+}
+
+// generic path for clouds larger than FPS_THREADS*8 points: minimum distances in global scratch
+__global__ __launch_bounds__(FPS_THREADS) void fps_kernel_large(int n, int m, int lg, const float* __restrict__ dataset,
+                                                                float* __restrict__ temp, int32_t* __restrict__ idxs) {
+  __shared__ unsigned long long s_key[2][FPS_WAVES];
+  const int bi = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* ds = dataset + (size_t)bi * n * 3;
+  float* tp = temp + (size_t)bi * n;
+  int32_t* out = idxs + (size_t)bi * m;
+  const uint32_t bs = 1u << lg, qn = (uint32_t)((n + (int)bs - 1) >> lg) + 1u;
+  for (int k = tid; k < n; k += FPS_THREADS) tp[k] = 1e10f;
+  int old = 0;
+  if (tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float ox = ds[old * 3], oy = ds[old * 3 + 1], oz = ds[old * 3 + 2];
+    unsigned long long best = 0ull;
+    for (int k = tid; k < n; k += FPS_THREADS) {
+      const float d = dist2(ox, oy, oz, ds[k * 3], ds[k * 3 + 1], ds[k * 3 + 2]);
+      const float d2 = fminf(d, tp[k]);
+      tp[k] = d2;
+      const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (0xFFFFFFFFu - fps_tie_key((uint32_t)k, lg, bs, qn));
+      best = key > best ? key : best;
+    }
+    best = wave_max_u64(best);
+    if (lane == 0) s_key[j & 1][wave] = best;
+    __syncthreads();
+    unsigned long long w = s_key[j & 1][lane & (FPS_WAVES - 1)];
+#pragma unroll
+    for (int o = FPS_WAVES / 2; o > 0; o >>= 1) {
+      const unsigned long long u = __shfl_xor(w, o);
+      w = u > w ? u : w;
+    }
+    const uint32_t tk = 0xFFFFFFFFu - (uint32_t)w;
+    const uint32_t r = tk / qn, q = tk - r * qn;
+    old = (int)((q << lg) + (lg ? (__brev(r) >> (32 - lg)) : 0u));
+    if (tid == 0) out[j] = old;
+  }
+}
+
+__global__ __launch_bounds__(256) void ball_query_kernel(int n, int m, int total_q, float radius2, int nsample,
+                                                         const float* __restrict__ new_xyz, const float* __restrict__ xyz,
+                                                         int32_t* __restrict__ idx) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + wave;          // global query = bi * m + p
+  if (qi >= total_q) return;
+  const int bi = qi / m;
+  const float* q = new_xyz + (size_t)qi * 3;
+  const float* pts = xyz + (size_t)bi * n * 3;
+  int32_t* o = idx + (size_t)qi * nsample;
+  const float qx = q[0], qy = q[1], qz = q[2];
+  int cnt = 0, first = 0;
+  for (int base = 0; base < n && cnt < nsample; base += 64) {
+    const int k = base + lane;
+    bool in = false;
+    if (k < n) {
+      const float dx = qx - pts[k * 3], dy = qy - pts[k * 3 + 1], dz = qz - pts[k * 3 + 2];
+      in = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < radius2;
+    }
+    const unsigned long long bal = __ballot(in);
+    if (bal) {
+      if (cnt == 0) first = base + __ffsll((long long)bal) - 1;
+      const int pos = cnt + (int)__popcll(bal & ((1ull << lane) - 1ull));
+      if (in && pos < nsample) o[pos] = k;
+      cnt += (int)__popcll(bal);
+    }
+  }
+  if (cnt > nsample) cnt = nsample;
+  const int pad = cnt > 0 ? first : 0;
+  for (int l = cnt + lane; l < nsample; l += 64) o[l] = pad;
+}
+
+__global__ void group_points_kernel(int c, int n, int npoints, int nsample, const float* __restrict__ points,
+                                    const int32_t* __restrict__ idx, float* __restrict__ out) {
+  const int bi = blockIdx.z, ci = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= npoints * nsample) return;
+  const int src = idx[(size_t)bi * npoints * nsample + e];
+  out[((size_t)bi * c + ci) * npoints * nsample + e] = points[((size_t)bi * c + ci) * n + src];
+}
+
+__global__ void group_points_grad_kernel(int c, int n, int npoints, int nsample, const float* __restrict__ grad_out,
+                                         const int32_t* __restrict__ idx, float* __restrict__ grad_points) {
+  const int bi = blockIdx.z, ci = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= npoints * nsample) return;
+  const int dst = idx[(size_t)bi * npoints * nsample + e];
+  unsafeAtomicAdd(&grad_points[((size_t)bi * c + ci) * n + dst], grad_out[((size_t)bi * c + ci) * npoints * nsample + e]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int u3d_furthest_point_sampling(int b, int n, int m, const float* points, float* temp, int32_t* idx, void* stream) {
+  if (b < 0 || n < 0 || m < 0) return 1;
+  if (b == 0 || m == 0) return 0;
+  if (n <= 0 || !points || !idx) return 1;
+  int lg = 0;
+  {  // opt_n_threads(n): 2^floor(log2 n) capped at 1024 (cuda_utils.h:10-14, evaluated like the reference, in double)
+    const int pow_2 = (int)(log((double)n) / log(2.0));
+    lg = pow_2 > 10 ? 10 : (pow_2 < 0 ? 0 : pow_2);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int ppt = (n + FPS_THREADS - 1) / FPS_THREADS;
+  const size_t lds = (size_t)n * 3 * sizeof(float);
+#define FPS(P) hipLaunchKernelGGL(fps_kernel<P>, dim3(b), dim3(FPS_THREADS), lds, s, n, m, lg, points, idx)
+  if (ppt <= 1) FPS(1);
+  else if (ppt <= 2) FPS(2);
+  else if (ppt <= 4) FPS(4);
+  else if (ppt <= 8) FPS(8);
+  else {
+    if (!temp) return 1;
+    hipLaunchKernelGGL(fps_kernel_large, dim3(b), dim3(FPS_THREADS), 0, s, n, m, lg, points, temp, idx);
+  }
+#undef FPS
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int u3d_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz, int32_t* idx,
+                   void* stream) {
+  if (b < 0 || n < 0 || m < 0 || nsample < 0) return 1;
+  if (b == 0 || m == 0 || nsample == 0) return 0;
+  if (!new_xyz || !xyz || !idx) return 1;
+  const int total = b * m;
+  hipLaunchKernelGGL(ball_query_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, n, m, total, radius * radius,
+                     nsample, new_xyz, xyz, idx);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int u3d_group_points(int b, int c, int n, int npoints, int nsample, const float* points, const int32_t* idx, float* out,
+                     void* stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0) return 1;
+  if (b == 0 || c == 0 || npoints * nsample == 0) return 0;
+  if (!points || !idx || !out) return 1;
+  hipLaunchKernelGGL(group_points_kernel, dim3((npoints * nsample + 255) / 256, c, b), dim3(256), 0, (hipStream_t)stream, c, n,
+                     npoints, nsample, points, idx, out);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int u3d_group_points_grad(int b, int c, int n, int npoints, int nsample, const float* grad_out, const int32_t* idx,
+                          float* grad_points, void* stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0) return 1;
+  if (b == 0 || c == 0 || npoints * nsample == 0) return 0;
+  if (!grad_out || !idx || !grad_points) return 1;
+  hipLaunchKernelGGL(group_points_grad_kernel, dim3((npoints * nsample + 255) / 256, c, b), dim3(256), 0, (hipStream_t)stream,
+                     c, n, npoints, nsample, grad_out, idx, grad_points);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// gather == group with nsample = 1
+int u3d_gather_points(int b, int c, int n, int npoints, const float* points, const int32_t* idx, float* out, void* stream) {
+  return u3d_group_points(b, c, n, npoints, 1, points, idx, out, stream);
+}
+
+int u3d_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out, const int32_t* idx, float* grad_points,
+                           void* stream) {
+  return u3d_group_points_grad(b, c, n, npoints, 1, grad_out, idx, grad_points, stream);
+}
+
+}  // extern "C"

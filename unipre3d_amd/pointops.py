@@ -1,0 +1,175 @@
+"""Point sampling / grouping operators with the reference's Python names and signatures:
+openpoints/models/layers/subsample.py:77-148 (`furthest_point_sample`, `gather_operation`, `fps`) and
+openpoints/models/layers/group.py:76-203 (`grouping_operation`, `ball_query`), and the `QueryAndGroup` module
+(:208-260).  Backed by libunipre3d_pointops.so (include/unipre3d_pointops.h); no CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunipre3d_pointops.so")
+EXPORTS = ("u3d_furthest_point_sampling", "u3d_ball_query", "u3d_group_points", "u3d_group_points_grad",
+           "u3d_gather_points", "u3d_gather_points_grad")
+_po = None
+
+
+def load() -> ctypes.CDLL:
+    global _po
+    if _po is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing (no fallback): run `make -C unipre3d_amd/csrc`")
+        lib = ctypes.CDLL(LIB_PATH)
+        vp, i, f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+        lib.u3d_furthest_point_sampling.argtypes = [i, i, i, vp, vp, vp, vp]
+        lib.u3d_ball_query.argtypes = [i, i, i, f, i, vp, vp, vp, vp]
+        lib.u3d_group_points.argtypes = [i, i, i, i, i, vp, vp, vp, vp]
+        lib.u3d_group_points_grad.argtypes = [i, i, i, i, i, vp, vp, vp, vp]
+        lib.u3d_gather_points.argtypes = [i, i, i, i, vp, vp, vp, vp]
+        lib.u3d_gather_points_grad.argtypes = [i, i, i, i, vp, vp, vp, vp]
+        for n in EXPORTS:
+            getattr(lib, n).restype = ctypes.c_int
+        _po = lib
+    return _po
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(t):
+    if t.device.type != "cuda":
+        raise RuntimeError("unipre3d_amd.pointops needs tensors on a HIP device; there is no CPU fallback")
+
+
+class FurthestPointSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+        """xyz (B,N,3) -> (B,npoint) int32 indices, starting from index 0 (subsample.py:77-100)."""
+        assert xyz.is_contiguous()
+        _need_gpu(xyz)
+        B, N, _ = xyz.size()
+        out = torch.empty(B, npoint, dtype=torch.int32, device=xyz.device)
+        temp = torch.empty(B, N, dtype=torch.float32, device=xyz.device) if N > 8192 else None
+        _check(load().u3d_furthest_point_sampling(B, N, npoint, _lib.ptr(xyz), _lib.ptr(temp), _lib.ptr(out), _stream()), "fps")
+        return out
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class GatherOperation(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """features (B,C,N), idx (B,npoint) -> (B,C,npoint) (subsample.py:110-131)."""
+        assert features.is_contiguous() and idx.is_contiguous()
+        _need_gpu(features)
+        B, npoint = idx.size()
+        _, C, N = features.size()
+        out = torch.empty(B, C, npoint, dtype=torch.float32, device=features.device)
+        _check(load().u3d_gather_points(B, C, N, npoint, _lib.ptr(features), _lib.ptr(idx), _lib.ptr(out), _stream()), "gather")
+        ctx.for_backwards = (idx, C, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, C, N = ctx.for_backwards
+        B, npoint = idx.size()
+        grad = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
+        g = grad_out.contiguous()
+        _check(load().u3d_gather_points_grad(B, C, N, npoint, _lib.ptr(g), _lib.ptr(idx), _lib.ptr(grad), _stream()), "gather grad")
+        return grad, None
+
+
+gather_operation = GatherOperation.apply
+
+
+def fps(data: torch.Tensor, number: int) -> torch.Tensor:
+    """data (B,N,C) -> the `number` furthest-point-sampled rows (subsample.py:151-160)."""
+    idx = furthest_point_sample(data[:, :, :3].contiguous(), number)
+    return torch.gather(data, 1, idx.unsqueeze(-1).long().expand(-1, -1, data.shape[-1]))
+
+
+class GroupingOperation(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample) (group.py:76-99)."""
+        assert features.is_contiguous() and idx.is_contiguous()
+        _need_gpu(features)
+        B, npoint, nsample = idx.size()
+        _, C, N = features.size()
+        out = torch.empty(B, C, npoint, nsample, dtype=torch.float32, device=features.device)
+        _check(load().u3d_group_points(B, C, N, npoint, nsample, _lib.ptr(features.float()), _lib.ptr(idx), _lib.ptr(out), _stream()),
+               "group")
+        ctx.for_backwards = (idx, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor) -> Tuple[torch.Tensor, None]:
+        idx, N = ctx.for_backwards
+        B, C, npoint, nsample = grad_out.size()
+        grad = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
+        g = grad_out.contiguous()
+        _check(load().u3d_group_points_grad(B, C, N, npoint, nsample, _lib.ptr(g), _lib.ptr(idx), _lib.ptr(grad), _stream()),
+               "group grad")
+        return grad, None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    @staticmethod
+    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+        """xyz (B,N,3) support, new_xyz (B,npoint,3) centres -> (B,npoint,nsample) int32 (group.py:175-196)."""
+        assert new_xyz.is_contiguous() and xyz.is_contiguous()
+        _need_gpu(xyz)
+        B, N, _ = xyz.size()
+        npoint = new_xyz.size(1)
+        idx = torch.empty(B, npoint, nsample, dtype=torch.int32, device=xyz.device)
+        _check(load().u3d_ball_query(B, N, npoint, float(radius), nsample, _lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(idx), _stream()),
+               "ball query")
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class QueryAndGroup(nn.Module):
+    """group.py:208-260 (relative_xyz / normalize_dp / return_only_idx options)."""
+
+    def __init__(self, radius: float, nsample: int, relative_xyz=True, normalize_dp=False, return_only_idx=False, **kwargs):
+        super().__init__()
+        self.radius, self.nsample = radius, nsample
+        self.relative_xyz, self.normalize_dp, self.return_only_idx = relative_xyz, normalize_dp, return_only_idx
+
+    def forward(self, query_xyz: torch.Tensor, support_xyz: torch.Tensor, features: torch.Tensor = None):
+        idx = ball_query(self.radius, self.nsample, support_xyz, query_xyz)
+        if self.return_only_idx:
+            return idx
+        grouped_xyz = grouping_operation(support_xyz.transpose(1, 2).contiguous(), idx)
+        if self.relative_xyz:
+            grouped_xyz = grouped_xyz - query_xyz.transpose(1, 2).unsqueeze(-1)
+            if self.normalize_dp:
+                grouped_xyz = grouped_xyz / self.radius
+        grouped_features = grouping_operation(features, idx) if features is not None else None
+        return grouped_xyz, grouped_features
