@@ -1,10 +1,10 @@
 // Point sampling / grouping operators for gfx950; semantics: oracle/pointops_oracle.c, which restates
 // openpoints/cpp/pointnet2_batch/src/{sampling,ball_query,group_points}_gpu.cu.
 //
-//  * furthest point sampling: one 1024-thread workgroup per cloud, coordinates staged once in LDS, per-point minimum
-//    distances kept in REGISTERS (the reference round-trips a (B,N) temp array through global memory every iteration),
-//    arg-max as a single u64 max over (distance bits << 32 | inverted tie key): DPP/shuffle within the wave, 16 wave
-//    results through double-buffered LDS => ONE barrier per selected point.  The tie key reproduces the order in which the
+//  * furthest point sampling: one 256- or 1024-thread workgroup per cloud, coordinates staged once in LDS, up to 32 points per
+//    thread with their running minimum distances in REGISTERS (the reference round-trips a (B,N) temp array through
+//    global memory every iteration), arg-max over (distance, inverted tie key): DPP row steps + 4 readlanes within the
+//    wave, 4 wave results through double-buffered LDS => ONE barrier per selected point.  The tie key reproduces the order in which the
 //    reference's shared-memory tree resolves equal distances for ITS block size, so the selection is bit-identical.
 //  * ball query: one WAVE per query (the reference: one thread per query scanning all N points serially): 64 candidates
 //    per step, ballot + popcount prefix keeps index order, early exit at nsample.
@@ -31,19 +31,47 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return v;
 }
 
-constexpr int FPS_THREADS = 1024;
-constexpr int FPS_WAVES = FPS_THREADS / 64;
-
-// tie key of point k for the reference's block size bs = 2^lg: equal distances are won by the smaller
-// (bit-reversed (k mod bs), k div bs)  [per-thread strided scan keeps the first maximum; the tree keeps the lower slot]
-__device__ __forceinline__ uint32_t fps_tie_key(uint32_t k, int lg, uint32_t bs, uint32_t qn) {
-  const uint32_t r = lg ? (__brev(k & (bs - 1)) >> (32 - lg)) : 0u;
-  return r * qn + (k >> lg);
+// (distance, inverted tie key) arg-max across the wave without the LDS crossbar: four DPP steps leave every lane with
+// its 16-lane row's winner, the four row winners are read into SGPRs and compared on the scalar unit.
+template <int CTRL>
+__device__ __forceinline__ void dpp_max_step(float& d, uint32_t& t) {
+  const float od = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), CTRL, 0xf, 0xf, false));
+  const uint32_t ot = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, CTRL, 0xf, 0xf, false);
+  const bool take = od > d || (od == d && ot > t);
+  d = take ? od : d;
+  t = take ? ot : t;
+}
+__device__ __forceinline__ unsigned long long wave_argmax(float d, uint32_t t) {
+  dpp_max_step<0xB1>(d, t);    // quad_perm [1,0,3,2]
+  dpp_max_step<0x4E>(d, t);    // quad_perm [2,3,0,1]
+  dpp_max_step<0x141>(d, t);   // row_half_mirror
+  dpp_max_step<0x140>(d, t);   // row_mirror
+  unsigned long long best = 0ull;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned long long k = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(__float_as_int(d), r * 16) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)t, r * 16);
+    best = k > best ? k : best;
+  }
+  return best;
 }
 
-template <int PPT>
+// tie key of point k for the reference's block size bs = 2^lg (lg <= 10): equal distances are won by the smaller
+// (bit-reversed (k mod bs), k div bs)  [per-thread strided scan keeps the first maximum; the tree keeps the lower slot].
+// Packed as r << 22 | q (q = k div bs < 2^22 for any n < 2^32 / ... in practice n < 4M * bs).
+__device__ __forceinline__ uint32_t fps_tie_key(uint32_t k, int lg, uint32_t bs) {
+  const uint32_t r = lg ? (__brev(k & (bs - 1)) >> (32 - lg)) : 0u;
+  return (r << 22) | (k >> lg);
+}
+__device__ __forceinline__ int fps_decode(uint32_t tk, int lg) {
+  const uint32_t r = tk >> 22, q = tk & 0x3FFFFFu;
+  return (int)((q << lg) + (lg ? (__brev(r) >> (32 - lg)) : 0u));
+}
+
+template <int FPS_THREADS, int PPT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int lg, const float* __restrict__ dataset,
                                                           int32_t* __restrict__ idxs) {
+  constexpr int FPS_WAVES = FPS_THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) float s_xyz[];   // [n][3]
   __shared__ unsigned long long s_key[2][FPS_WAVES];
   const int bi = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -51,7 +79,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int lg, 
   int32_t* out = idxs + (size_t)bi * m;
   for (int i = tid; i < n * 3; i += FPS_THREADS) s_xyz[i] = ds[i];
   __syncthreads();
-  const uint32_t bs = 1u << lg, qn = (uint32_t)((n + (int)bs - 1) >> lg) + 1u;
+  const uint32_t bs = 1u << lg;
   float x[PPT], y[PPT], z[PPT], t[PPT];
   uint32_t inv_tk[PPT];
 #pragma unroll
@@ -59,49 +87,47 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int lg, 
     const int k = tid + i * FPS_THREADS;
     const bool v = k < n;
     x[i] = v ? s_xyz[k * 3] : 0.f; y[i] = v ? s_xyz[k * 3 + 1] : 0.f; z[i] = v ? s_xyz[k * 3 + 2] : 0.f;
-    t[i] = 1e10f;
-    inv_tk[i] = v ? 0xFFFFFFFFu - fps_tie_key((uint32_t)k, lg, bs, qn) : 0u;
+    t[i] = v ? 1e10f : 0.f;                        // padding slots: distance 0 and the lowest key, never beat a real point
+    inv_tk[i] = v ? 0xFFFFFFFFu - fps_tie_key((uint32_t)k, lg, bs) : 0u;
   }
   int old = 0;
   if (tid == 0) out[0] = 0;
   for (int j = 1; j < m; ++j) {
     const float ox = s_xyz[old * 3], oy = s_xyz[old * 3 + 1], oz = s_xyz[old * 3 + 2];
-    unsigned long long best = 0ull;
+    float bd = -1.f;
+    uint32_t bt = 0u;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      const int k = tid + i * FPS_THREADS;
-      if (k < n) {
-        const float d = dist2(ox, oy, oz, x[i], y[i], z[i]);
-        t[i] = fminf(d, t[i]);
-        const unsigned long long key = ((unsigned long long)__float_as_uint(t[i]) << 32) | inv_tk[i];
-        best = key > best ? key : best;
-      }
+      const float d = dist2(ox, oy, oz, x[i], y[i], z[i]);
+      t[i] = fminf(d, t[i]);
+      const bool take = t[i] > bd || (t[i] == bd && inv_tk[i] > bt);
+      bd = take ? t[i] : bd;
+      bt = take ? inv_tk[i] : bt;
     }
-    best = wave_max_u64(best);
+    const unsigned long long best = wave_argmax(bd, bt);
     if (lane == 0) s_key[j & 1][wave] = best;
     __syncthreads();
-    unsigned long long w = s_key[j & 1][lane & (FPS_WAVES - 1)];
+    unsigned long long w = s_key[j & 1][0];
 #pragma unroll
-    for (int o = FPS_WAVES / 2; o > 0; o >>= 1) {
-      const unsigned long long u = __shfl_xor(w, o);
+    for (int q = 1; q < FPS_WAVES; ++q) {
+      const unsigned long long u = s_key[j & 1][q];
       w = u > w ? u : w;
     }
-    const uint32_t tk = 0xFFFFFFFFu - (uint32_t)w;
-    const uint32_t r = tk / qn, q = tk - r * qn;
-    old = (int)((q << lg) + (lg ? (__brev(r) >> (32 - lg)) : 0u));
+    old = fps_decode(0xFFFFFFFFu - (uint32_t)w, lg);
     if (tid == 0) out[j] = old;
   }
 }
 
 // generic path for clouds larger than FPS_THREADS*8 points: minimum distances in global scratch
-__global__ __launch_bounds__(FPS_THREADS) void fps_kernel_large(int n, int m, int lg, const float* __restrict__ dataset,
-                                                                float* __restrict__ temp, int32_t* __restrict__ idxs) {
+__global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int lg, const float* __restrict__ dataset,
+                                                         float* __restrict__ temp, int32_t* __restrict__ idxs) {
+  constexpr int FPS_THREADS = 1024, FPS_WAVES = 16;
   __shared__ unsigned long long s_key[2][FPS_WAVES];
   const int bi = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* ds = dataset + (size_t)bi * n * 3;
   float* tp = temp + (size_t)bi * n;
   int32_t* out = idxs + (size_t)bi * m;
-  const uint32_t bs = 1u << lg, qn = (uint32_t)((n + (int)bs - 1) >> lg) + 1u;
+  const uint32_t bs = 1u << lg;
   for (int k = tid; k < n; k += FPS_THREADS) tp[k] = 1e10f;
   int old = 0;
   if (tid == 0) out[0] = 0;
@@ -112,21 +138,19 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel_large(int n, int m, in
       const float d = dist2(ox, oy, oz, ds[k * 3], ds[k * 3 + 1], ds[k * 3 + 2]);
       const float d2 = fminf(d, tp[k]);
       tp[k] = d2;
-      const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (0xFFFFFFFFu - fps_tie_key((uint32_t)k, lg, bs, qn));
+      const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (0xFFFFFFFFu - fps_tie_key((uint32_t)k, lg, bs));
       best = key > best ? key : best;
     }
     best = wave_max_u64(best);
     if (lane == 0) s_key[j & 1][wave] = best;
     __syncthreads();
-    unsigned long long w = s_key[j & 1][lane & (FPS_WAVES - 1)];
+    unsigned long long w = s_key[j & 1][0];
 #pragma unroll
-    for (int o = FPS_WAVES / 2; o > 0; o >>= 1) {
-      const unsigned long long u = __shfl_xor(w, o);
+    for (int q = 1; q < FPS_WAVES; ++q) {
+      const unsigned long long u = s_key[j & 1][q];
       w = u > w ? u : w;
     }
-    const uint32_t tk = 0xFFFFFFFFu - (uint32_t)w;
-    const uint32_t r = tk / qn, q = tk - r * qn;
-    old = (int)((q << lg) + (lg ? (__brev(r) >> (32 - lg)) : 0u));
+    old = fps_decode(0xFFFFFFFFu - (uint32_t)w, lg);
     if (tid == 0) out[j] = old;
   }
 }
@@ -195,16 +219,18 @@ int u3d_furthest_point_sampling(int b, int n, int m, const float* points, float*
     lg = pow_2 > 10 ? 10 : (pow_2 < 0 ? 0 : pow_2);
   }
   hipStream_t s = (hipStream_t)stream;
-  const int ppt = (n + FPS_THREADS - 1) / FPS_THREADS;
   const size_t lds = (size_t)n * 3 * sizeof(float);
-#define FPS(P) hipLaunchKernelGGL(fps_kernel<P>, dim3(b), dim3(FPS_THREADS), lds, s, n, m, lg, points, idx)
-  if (ppt <= 1) FPS(1);
-  else if (ppt <= 2) FPS(2);
-  else if (ppt <= 4) FPS(4);
-  else if (ppt <= 8) FPS(8);
+#define FPS(T, P) hipLaunchKernelGGL((fps_kernel<T, P>), dim3(b), dim3(T), lds, s, n, m, lg, points, idx)
+  // small clouds: 4 waves keep the per-sample dependency chain short; larger ones spread over 16 waves
+  if (n <= 256) FPS(256, 1);
+  else if (n <= 512) FPS(256, 2);
+  else if (n <= 1024) FPS(256, 4);
+  else if (n <= 2048) FPS(1024, 2);
+  else if (n <= 4096) FPS(1024, 4);
+  else if (n <= 8192) FPS(1024, 8);
   else {
     if (!temp) return 1;
-    hipLaunchKernelGGL(fps_kernel_large, dim3(b), dim3(FPS_THREADS), 0, s, n, m, lg, points, temp, idx);
+    hipLaunchKernelGGL(fps_kernel_large, dim3(b), dim3(1024), 0, s, n, m, lg, points, temp, idx);
   }
 #undef FPS
   return hipGetLastError() == hipSuccess ? 0 : 3;
