@@ -248,7 +248,7 @@ def _read_num_rendered(g, batch, H, W, t) -> float:
     B, P = g["xyz"].shape[:2]
     V = batch.world_view.shape[1]
     dev = g["xyz"].device
-    plan = _Plan(B, V, P, H, W, t, t, 1.0, 1, 4, _lib.FLAG_ANTIALIASING)
+    plan = _Plan(B, V, P, H, W, t, t, 1.0, 1, 4, _lib.FLAG_ANTIALIASING | _lib.FLAG_STATS)
     NV = B * V
     color = torch.empty((NV, 3, H, W), device=dev); radii = torch.zeros((NV, P), dtype=torch.int32, device=dev)
     geom = torch.empty(plan.sizes.geom_bytes, dtype=torch.uint8, device=dev)

@@ -166,7 +166,7 @@ int u3d_rasterize_forward(const u3d_raster_desc* desc, const float* bg, const fl
   hipStream_t s = (hipStream_t)stream;
   U3DBuffers b{};
   u3d_carve(d, geom, binning, image, &b);
-  (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
+  if (d.flags & U3D_FLAG_STATS) (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
   if (d.P == 0) (void)hipMemsetAsync(b.n_vis, 0, sizeof(uint32_t) * NV, s);   // the sort writes n_vis whenever P > 0
   if (d.P > 0) {
     {
@@ -247,7 +247,7 @@ int u3d_render_loss_forward(const u3d_raster_desc* desc, const u3d_head_desc* he
   u3d_carve(d, geom, binning, image, &b);
   U3DFused f{};
   u3d_carve_fused(d, fused, &f);
-  (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
+  if (d.flags & U3D_FLAG_STATS) (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
   if (head->mode == 1) u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, s);
   {
     ProfScope ps(0, s);
@@ -326,7 +326,7 @@ int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head,
   u3d_carve_fused(d, fused, &f);
   double* acc = (double*)backward_scratch;
   float* part = (float*)((char*)backward_scratch + Lay.acc_bytes);
-  (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
+  if (d.flags & U3D_FLAG_STATS) (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
   (void)hipMemsetAsync(acc, 0, Lay.acc_bytes, s);
   (void)hipMemsetAsync(f.qdot, 0, sizeof(float) * 4 * d.n_items, s);
   if (head->mode == 1) u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, s);

@@ -163,22 +163,58 @@ __device__ __forceinline__ void load_gaussian(const U3DSource& src, int item, si
 
 template <int D>
 __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
-    int P, int vpi, int H, int W, float tanx, float tany, float mod, int flags, U3DSource src,
+    int P, int vpi, int vpt, int H, int W, float tanx, float tany, float mod, int flags, U3DSource src,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     int32_t* __restrict__ radii, float* __restrict__ depth, float2* __restrict__ xy, float4* __restrict__ conic_op,
     float4* __restrict__ rgbd, uint2* __restrict__ rect, uint32_t* __restrict__ clamped,
     uint32_t* __restrict__ num_rendered) {
-  const int view = blockIdx.y;
-  const int i = blockIdx.x * U3D_BLOCK + threadIdx.x;
+  // One thread = one Gaussian of set blockIdx.y; it walks the views [v0, v1) of that set, so the view-independent work
+  // (head activations, Sigma, SH coefficient fetch) is done once.  blockIdx.z splits the views when P is small.
+  extern __shared__ __attribute__((aligned(16))) float s_rec[];   // fused mode: this block's head records, staged coalesced
+  constexpr int K = (D + 1) * (D + 1);
+  const int item = blockIdx.y;
+  const int i0 = blockIdx.x * U3D_BLOCK;
+  const int i = i0 + threadIdx.x;
+  const int v0 = blockIdx.z * vpt, v1 = min(vpi, v0 + vpt);
+  U3DSource lsrc = src;
+  size_t gi = (size_t)item * P + (i < P ? i : 0);
+  if (src.act != 0) {
+    // rows i0 .. i0+255 of head_out are contiguous: coalesced copy into LDS, then row-strided reads (C odd: no conflicts)
+    const int C = src.s_means;
+    const int nrow = min(U3D_BLOCK, P - i0);
+    const float* rows = src.means + ((size_t)item * P + i0) * C;
+    for (int e = threadIdx.x; e < nrow * C; e += U3D_BLOCK) s_rec[e] = rows[e];
+    __syncthreads();
+    lsrc.means = s_rec; lsrc.opac = s_rec + 3; lsrc.scales = s_rec + 4; lsrc.rots = s_rec + 7; lsrc.shs = s_rec + 11;
+    lsrc.center = src.center + ((size_t)item * P + i0) * 3;
+  }
+  uint32_t touched_local[1] = {0};
+  (void)touched_local;
+  GaussIn gin;
+  float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float shc[K * 3];
+  if (i < P) {
+    const size_t li = src.act != 0 ? (size_t)threadIdx.x : gi;     // index into the (possibly LDS-resident) source
+    load_gaussian(lsrc, item, li, gin);
+    if (src.cov) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) c6[k] = src.cov[gi * 6 + k];
+    } else {
+      cov3d_from_scale_rot(gin.s, mod, gin.q, c6);
+    }
+    if (!src.colors) {
+      const float* sh = lsrc.shs + li * (size_t)lsrc.s_shs;
+#pragma unroll
+      for (int k = 0; k < K * 3; ++k) shc[k] = sh[k];
+    }
+  }
+  for (int vk = v0; vk < v1; ++vk) {
+  const int view = item * vpi + vk;
   uint32_t touched = 0;
   if (i < P) {
     const size_t g = (size_t)view * P + i;
-    const int item = view / vpi;
-    const size_t gi = (size_t)item * P + i;
     Cam cam;
     load_cam(cam, viewmatrix, projmatrix, campos, view);
-    GaussIn gin;
-    load_gaussian(src, item, gi, gin);
     const float* p = gin.p;
     int radius = 0;
     float zv = cam.V[2] * p[0] + cam.V[6] * p[1] + cam.V[10] * p[2] + cam.V[14];
@@ -191,13 +227,6 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
 #pragma unroll
       for (int j = 0; j < 4; ++j) hom[j] = cam.Pm[j] * p[0] + cam.Pm[4 + j] * p[1] + cam.Pm[8 + j] * p[2] + cam.Pm[12 + j];
       const float p_w = 1.0f / (hom[3] + 0.0000001f);
-      float c6[6];
-      if (src.cov) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c6[k] = src.cov[gi * 6 + k];
-      } else {
-        cov3d_from_scale_rot(gin.s, mod, gin.q, c6);
-      }
       const float fx = (float)W / (2.f * tanx), fy = (float)H / (2.f * tany);
       Ewa e;
       ewa_setup(e, p, cam, fx, fy, tanx, tany);
@@ -230,7 +259,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
             float dir[3] = {p[0] - cam.pos[0], p[1] - cam.pos[1], p[2] - cam.pos[2]};
             const float inv = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
             dir[0] *= inv; dir[1] *= inv; dir[2] *= inv;
-            sh_to_rgb<D>(src.shs + gi * (size_t)src.s_shs, dir, rgb, cb);
+            sh_to_rgb<D>(shc, dir, rgb, cb);
           }
           radius = r;
           touched = (uint32_t)nt;
@@ -249,10 +278,13 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     rect[g] = rc;
     clamped[g] = cb;
   }
-  // statistics: num_rendered[view] += sum(tiles touched)   (wave reduce, one atomic per wave)
+  // statistics (U3D_FLAG_STATS only): num_rendered[view] += sum(tiles touched), wave reduce + one atomic per wave
+  if (flags & U3D_FLAG_STATS) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) touched += __shfl_xor(touched, o);
-  if ((threadIdx.x & 63) == 0 && touched) atomicAdd(&num_rendered[view], touched);
+    for (int o = 32; o > 0; o >>= 1) touched += __shfl_xor(touched, o);
+    if ((threadIdx.x & 63) == 0 && touched) atomicAdd(&num_rendered[view], touched);
+  }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -599,13 +631,16 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 
 void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, int32_t* radii, hipStream_t s) {
-  const int NV = d.n_items * d.views_per_item;
-  dim3 grid((d.P + U3D_BLOCK - 1) / U3D_BLOCK, NV), block(U3D_BLOCK);
+  // enough Gaussians to fill the chip by themselves -> one thread walks all views of its set; otherwise split the views
+  const int vpt = ((size_t)d.P * d.n_items >= 65536) ? d.views_per_item : 1;
+  const int chunks = (d.views_per_item + vpt - 1) / vpt;
+  dim3 grid((d.P + U3D_BLOCK - 1) / U3D_BLOCK, d.n_items, chunks), block(U3D_BLOCK);
+  const size_t lds = src.act != 0 ? (size_t)U3D_BLOCK * src.s_means * sizeof(float) : 0;
   const int D = src.shs ? d.sh_degree : 0;
 #define LAUNCH(DEG)                                                                                                   \
-  hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, 0, s, d.P, d.views_per_item, d.image_height, d.image_width, \
-                     d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, src, viewmatrix, projmatrix, campos, radii, b.depth, \
-                     b.xy, b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered)
+  hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, lds, s, d.P, d.views_per_item, vpt, d.image_height,     \
+                     d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, src, viewmatrix, projmatrix, campos, \
+                     radii, b.depth, b.xy, b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered)
   switch (D) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;

@@ -84,18 +84,24 @@ __global__ __launch_bounds__(U3D_BLOCK) void radix_hist_kernel(int pass, int P, 
     }
   }
   __syncthreads();
-  hist[((size_t)view * 256 + threadIdx.x) * nblk + blk] = h[threadIdx.x];
+  hist[((size_t)view * nblk + blk) * 256 + threadIdx.x] = h[threadIdx.x];   // [view][block][digit]: coalesced
 }
 
+// hist[view][blk][digit] (counts) -> global exclusive offsets in (digit-major, block-minor) order, in place.
+// One workgroup per view, thread = digit; both sweeps read coalesced rows whose loads do not depend on the running sum.
 __global__ __launch_bounds__(U3D_BLOCK) void radix_scan_kernel(int nblk, uint32_t* __restrict__ hist) {
   __shared__ uint32_t tot[256];
   const int view = blockIdx.x, d = threadIdx.x;
-  uint32_t* row = hist + ((size_t)view * 256 + d) * nblk;
-  uint32_t s = 0;
-  for (int b = 0; b < nblk; ++b) s += row[b];
+  uint32_t* col = hist + (size_t)view * nblk * 256 + d;
+  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int b = 0;
+  for (; b + 3 < nblk; b += 4) {
+    s0 += col[(size_t)b * 256]; s1 += col[(size_t)(b + 1) * 256]; s2 += col[(size_t)(b + 2) * 256]; s3 += col[(size_t)(b + 3) * 256];
+  }
+  for (; b < nblk; ++b) s0 += col[(size_t)b * 256];
+  const uint32_t s = (s0 + s1) + (s2 + s3);
   tot[d] = s;
   __syncthreads();
-  // exclusive scan over 256 digit totals (Hillis-Steele in LDS)
   for (int o = 1; o < 256; o <<= 1) {
     const uint32_t v = d >= o ? tot[d - o] : 0u;
     __syncthreads();
@@ -103,9 +109,18 @@ __global__ __launch_bounds__(U3D_BLOCK) void radix_scan_kernel(int nblk, uint32_
     __syncthreads();
   }
   uint32_t off = tot[d] - s;
-  for (int b = 0; b < nblk; ++b) {
-    const uint32_t c = row[b];
-    row[b] = off;
+  b = 0;
+  for (; b + 3 < nblk; b += 4) {
+    const uint32_t c0 = col[(size_t)b * 256], c1 = col[(size_t)(b + 1) * 256], c2 = col[(size_t)(b + 2) * 256],
+                   c3 = col[(size_t)(b + 3) * 256];
+    col[(size_t)b * 256] = off; off += c0;
+    col[(size_t)(b + 1) * 256] = off; off += c1;
+    col[(size_t)(b + 2) * 256] = off; off += c2;
+    col[(size_t)(b + 3) * 256] = off; off += c3;
+  }
+  for (; b < nblk; ++b) {
+    const uint32_t c = col[(size_t)b * 256];
+    col[(size_t)b * 256] = off;
     off += c;
   }
 }
@@ -123,7 +138,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void radix_scatter_kernel(int pass, int 
   const int wave = tid >> 6;
   const uint32_t lane = u3d_lane_id();
   const size_t base = (size_t)view * P;
-  digit_base[tid] = hist[((size_t)view * 256 + tid) * nblk + blk];
+  digit_base[tid] = hist[((size_t)view * nblk + blk) * 256 + tid];
 #pragma unroll
   for (int w = 0; w < 4; ++w) wave_cnt[w][tid] = 0;
   __syncthreads();
