@@ -185,7 +185,9 @@ def main():
         # R from the Gaussian rects: visible Gaussians x tiles touched is accumulated by the kernel; read it back via radii>0
         # (exact value is in the geom scratch; recompute from an extra forward on a fresh plan for reporting)
         from unipre3d_amd.rasterizer import _Plan
-        R_mean = _read_num_rendered(g, batch, H, W, t)
+        with torch.no_grad():   # R of the Gaussians the timed steps actually rendered (from head_out, not batch.raw)
+            g_used = synthetic.gaussians_from_batch(synthetic.SyntheticBatch(**dict(batch.__dict__, raw=head_out.detach().permute(0, 2, 1))))
+        R_mean = _read_num_rendered(g_used, batch, H, W, t)
         NV = B * V
         kernels = {}
         for k, (ms, cnt) in prof.items():

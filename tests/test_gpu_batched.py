@@ -176,3 +176,24 @@ def test_backward_is_run_to_run_deterministic():
                 assert torch.equal(g, grads[0][1])
             else:
                 assert rel_l2(g.cpu().numpy(), grads[0][1].cpu().numpy()) < tol
+
+
+def test_fused_sh_degree0_and_uneven_shapes():
+    """C = 14 channels (max_sh_degree 0), P not a multiple of 64/256, image not a multiple of 16, 1 view per object."""
+    from unipre3d_amd import fused, head, losses, renderer, synthetic
+    b, bd = _batch(3, 77, 1, 50, 70, seed=21)
+    h14 = bd.raw.permute(0, 2, 1)[..., :14].contiguous().requires_grad_(True)
+    loss, img, radii = fused.render_loss_fused(h14, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt, bd.bg, bd.fov_deg,
+                                               50, 70, max_sh_degree=0, loss_kind="focal_l2", debug=True)
+    loss.backward()
+    raw = bd.raw[:, :14].clone().requires_grad_(True)
+    g = head.process_object_output(raw, bd.center, 1.0, max_sh_degree=0)
+    out = renderer.render_views(g, bd.world_view, bd.full_proj, bd.camera_center, bd.bg, bd.fov_deg, 50, 70, max_sh_degree=0)
+    lu = losses.render_loss(out, bd.gt.reshape(3, 3, 50, 70), "focal_l2")
+    lu.backward()
+    assert img.shape == (3, 3, 50, 70) and radii.shape == (3, 77)
+    assert rel_l2(img.cpu().numpy(), out.detach().cpu().numpy()) < 1e-5 and abs(loss.item() - lu.item()) < 1e-6
+    assert rel_l2(h14.grad.cpu().numpy(), raw.grad.permute(0, 2, 1).cpu().numpy()) < TOL
+    with pytest.raises(ValueError):
+        fused.render_loss_fused(h14, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt, bd.bg, bd.fov_deg, 50, 70,
+                                max_sh_degree=1)
