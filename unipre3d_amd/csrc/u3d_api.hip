@@ -172,7 +172,7 @@ int u3d_rasterize_forward(const u3d_raster_desc* desc, const float* bg, const fl
     {
       ProfScope ps(0, s);
       u3d_launch_preprocess_fwd(d, b, plain_source(d, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp),
-                                viewmatrix, projmatrix, campos, radii, s);
+                                viewmatrix, projmatrix, campos, radii, nullptr, s);
     }
     {
       ProfScope ps(1, s);
@@ -248,10 +248,11 @@ int u3d_render_loss_forward(const u3d_raster_desc* desc, const u3d_head_desc* he
   U3DFused f{};
   u3d_carve_fused(d, fused, &f);
   if (d.flags & U3D_FLAG_STATS) (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
-  if (head->mode == 1) u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, s);
+  if (head->mode == 1) u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, nullptr, s);
   {
     ProfScope ps(0, s);
-    u3d_launch_preprocess_fwd(d, b, head_source(d, *head, head_out, center, f.qnorm), viewmatrix, projmatrix, campos, radii, s);
+    u3d_launch_preprocess_fwd(d, b, head_source(d, *head, head_out, center, f.qnorm), viewmatrix, projmatrix, campos, radii,
+                              nullptr, s);
   }
   {
     ProfScope ps(1, s);
@@ -327,13 +328,12 @@ int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head,
   double* acc = (double*)backward_scratch;
   float* part = (float*)((char*)backward_scratch + Lay.acc_bytes);
   if (d.flags & U3D_FLAG_STATS) (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
-  (void)hipMemsetAsync(acc, 0, Lay.acc_bytes, s);
-  (void)hipMemsetAsync(f.qdot, 0, sizeof(float) * 4 * d.n_items, s);
-  if (head->mode == 1) u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, s);
+  // no memset nodes: quat_norms clears qdot, preprocess_fwd clears the accumulators of the (view, Gaussian) it projects
+  if (head->mode == 1) u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, f.qdot, s);
   const U3DSource src = head_source(d, *head, head_out, center, f.qnorm);
   {
     ProfScope ps(0, s);
-    u3d_launch_preprocess_fwd(d, b, src, viewmatrix, projmatrix, campos, radii, s);
+    u3d_launch_preprocess_fwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, s);
   }
   {
     ProfScope ps(1, s);
@@ -343,9 +343,9 @@ int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head,
   const U3DLoss L = make_loss(d, *loss, gt, f.partial, nullptr);
   {
     ProfScope ps(5, s);
-    u3d_launch_render_fb(d, b, bg, out_color, L, acc, part, s);
+    u3d_launch_render_fb(d, b, bg, out_color, L, acc, part, loss_out, s);   // + partial reduce + loss reduce
   }
-  u3d_launch_loss_reduce(NV * T, f.partial, L.inv_count, loss_out, s);
+  (void)T;
   U3DGradSink sink{};
   sink.means = d_head_out; sink.opac = d_head_out + 3; sink.scales = d_head_out + 4; sink.rots = d_head_out + 7;
   sink.shs = d_head_out + 11; sink.colors = nullptr; sink.cov = nullptr; sink.means2D = nullptr; sink.qdot = f.qdot;

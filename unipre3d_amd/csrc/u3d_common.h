@@ -151,11 +151,11 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
 
 // launchers (one per translation unit)
 void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
-                               const float* projmatrix, const float* campos, int32_t* radii, hipStream_t s);
+                               const float* projmatrix, const float* campos, int32_t* radii, double* acc_zero, hipStream_t s);
 void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, const int32_t* radii, const double* acc,
                                const U3DGradSink& sink, hipStream_t s);
-void u3d_launch_quat_norms(int n_items, int P, const float* rots, int s_rots, float* qnorm, hipStream_t s);
+void u3d_launch_quat_norms(int n_items, int P, const float* rots, int s_rots, float* qnorm, float* qdot_zero, hipStream_t s);
 void u3d_launch_quat_fixup(int n_items, int P, const float* rots, int s_rots, const float* qnorm, const float* qdot,
                            float* d_rots, hipStream_t s);
 void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const int32_t* radii, hipStream_t s);
@@ -165,7 +165,7 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
                            const float* dL_dinvdepth, const float* out_color, const U3DLoss& loss, double* acc,
                            float* part, hipStream_t s);
 void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,
-                          const U3DLoss& loss, double* acc, float* part, hipStream_t s);
+                          const U3DLoss& loss, double* acc, float* part, float* loss_out, hipStream_t s);
 void u3d_launch_loss_reduce(int n, const float* partial, float inv_count, float* loss_out, hipStream_t s);
 
 #ifdef __HIPCC__

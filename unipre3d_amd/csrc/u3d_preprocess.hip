@@ -167,7 +167,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     int32_t* __restrict__ radii, float* __restrict__ depth, float2* __restrict__ xy, float4* __restrict__ conic_op,
     float4* __restrict__ rgbd, uint2* __restrict__ rect, uint32_t* __restrict__ clamped,
-    uint32_t* __restrict__ num_rendered) {
+    uint32_t* __restrict__ num_rendered, double* __restrict__ acc_zero, size_t NG) {
   // One thread = one Gaussian of set blockIdx.y; it walks the views [v0, v1) of that set, so the view-independent work
   // (head activations, Sigma, SH coefficient fetch) is done once.  blockIdx.z splits the views when P is small.
   extern __shared__ __attribute__((aligned(16))) float s_rec[];   // fused mode: this block's head records, staged coalesced
@@ -277,6 +277,10 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     rgbd[g] = col;
     rect[g] = rc;
     clamped[g] = cb;
+    if (acc_zero) {   // single-pass training step: clear this (view, Gaussian)'s gradient accumulators here (saves a memset node)
+#pragma unroll
+      for (int k = 0; k < U3D_NACC; ++k) acc_zero[(size_t)k * NG + g] = 0.0;
+    }
   }
   // statistics (U3D_FLAG_STATS only): num_rendered[view] += sum(tiles touched), wave reduce + one atomic per wave
   if (flags & U3D_FLAG_STATS) {
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
 
 // across-point quaternion norms: qnorm[item][c] = || raw_rot[item, :, c] ||_2   (F.normalize(x(B,4,N), dim=-1))
 __global__ __launch_bounds__(U3D_BLOCK) void quat_norms_kernel(int P, const float* __restrict__ rots, int s_rots,
-                                                               float* __restrict__ qnorm) {
+                                                               float* __restrict__ qnorm, float* __restrict__ qdot_zero) {
   __shared__ float sm[4][4];
   const int item = blockIdx.x;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -601,7 +605,10 @@ __global__ __launch_bounds__(U3D_BLOCK) void quat_norms_kernel(int P, const floa
     if (lane == 0) sm[wave][k] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 4) qnorm[item * 4 + threadIdx.x] = sqrtf(sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+  if (threadIdx.x < 4) {
+    qnorm[item * 4 + threadIdx.x] = sqrtf(sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    if (qdot_zero) qdot_zero[item * 4 + threadIdx.x] = 0.f;
+  }
 }
 
 // second term of the across-point normalise backward: d x_i -= x_i * (sum_j x_j g_j) / n^3  when n > eps
@@ -630,7 +637,8 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 }  // namespace
 
 void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
-                               const float* projmatrix, const float* campos, int32_t* radii, hipStream_t s) {
+                               const float* projmatrix, const float* campos, int32_t* radii, double* acc_zero, hipStream_t s) {
+  const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
   // enough Gaussians to fill the chip by themselves -> one thread walks all views of its set; otherwise split the views
   const int vpt = ((size_t)d.P * d.n_items >= 65536) ? d.views_per_item : 1;
   const int chunks = (d.views_per_item + vpt - 1) / vpt;
@@ -640,7 +648,7 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 #define LAUNCH(DEG)                                                                                                   \
   hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, lds, s, d.P, d.views_per_item, vpt, d.image_height,     \
                      d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, src, viewmatrix, projmatrix, campos, \
-                     radii, b.depth, b.xy, b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered)
+                     radii, b.depth, b.xy, b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered, acc_zero, NG)
   switch (D) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;
@@ -669,8 +677,8 @@ void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 #undef LAUNCH
 }
 
-void u3d_launch_quat_norms(int n_items, int P, const float* rots, int s_rots, float* qnorm, hipStream_t s) {
-  hipLaunchKernelGGL(quat_norms_kernel, dim3(n_items), dim3(U3D_BLOCK), 0, s, P, rots, s_rots, qnorm);
+void u3d_launch_quat_norms(int n_items, int P, const float* rots, int s_rots, float* qnorm, float* qdot_zero, hipStream_t s) {
+  hipLaunchKernelGGL(quat_norms_kernel, dim3(n_items), dim3(U3D_BLOCK), 0, s, P, rots, s_rots, qnorm, qdot_zero);
 }
 
 void u3d_launch_quat_fixup(int n_items, int P, const float* rots, int s_rots, const float* qnorm, const float* qdot,

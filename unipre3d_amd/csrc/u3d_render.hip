@@ -921,7 +921,31 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
 __global__ __launch_bounds__(U3D_NACC * U3D_WAVE) void bwd_reduce_kernel(int P, int T, int NK, size_t NG,
                                                                         const uint32_t* __restrict__ sorted_id,
                                                                         const float* __restrict__ part,
-                                                                        double* __restrict__ acc) {
+                                                                        double* __restrict__ acc, int n_loss,
+                                                                        const float* __restrict__ loss_partial, float inv_count,
+                                                                        float* __restrict__ loss_out) {
+  if (blockIdx.y == BWD_REDUCE_SPLIT) {
+    // extra row of the grid: fixed-order sum of the per-tile loss partials (replaces a separate launch)
+    if (blockIdx.x != 0) return;
+    __shared__ float sm[U3D_NACC * U3D_WAVE];
+    constexpr int NT = U3D_NACC * U3D_WAVE;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = threadIdx.x;
+    for (; i + 3 * NT < n_loss; i += 4 * NT) {
+      a0 += loss_partial[i]; a1 += loss_partial[i + NT]; a2 += loss_partial[i + 2 * NT]; a3 += loss_partial[i + 3 * NT];
+    }
+    for (; i < n_loss; i += NT) a0 += loss_partial[i];
+    sm[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float v = 0.f;
+      for (int j = threadIdx.x; j < NT; j += 64) v += sm[j];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (threadIdx.x == 0) loss_out[0] = v * inv_count;
+    }
+    return;
+  }
   const int view = blockIdx.x, k = threadIdx.x >> 6, sp = threadIdx.x & 63;
   if (k >= NK) return;
   const int per = (T + BWD_REDUCE_SPLIT - 1) / BWD_REDUCE_SPLIT;
@@ -1001,7 +1025,7 @@ void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
 }
 
 void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,
-                          const U3DLoss& loss, double* acc, float* part, hipStream_t s) {
+                          const U3DLoss& loss, double* acc, float* part, float* loss_out, hipStream_t s) {
   const int tiles_x = (d.image_width + U3D_TILE - 1) / U3D_TILE, tiles_y = (d.image_height + U3D_TILE - 1) / U3D_TILE;
   const int T = tiles_x * tiles_y;
   const uint32_t nblocks = (uint32_t)(d.n_items * d.views_per_item * T);
@@ -1011,8 +1035,8 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
   hipLaunchKernelGGL(render_fb_wave_kernel, dim3(nwg), dim3(BWD_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
                      tiles_x, T, nblocks, nwg, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
                      acc, part, loss);
-  hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, BWD_REDUCE_SPLIT), dim3(U3D_NACC * U3D_WAVE), 0, s, d.P,
-                     T, U3D_NACC - 1, NG, b.sorted_id, part, acc);
+  hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, BWD_REDUCE_SPLIT + 1), dim3(U3D_NACC * U3D_WAVE), 0, s,
+                     d.P, T, U3D_NACC - 1, NG, b.sorted_id, part, acc, (int)nblocks, loss.partial, loss.inv_count, loss_out);
 }
 
 void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, const float* dL_dcolor,
@@ -1036,7 +1060,7 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
                          dL_dinvdepth, b.final_T, b.n_contrib, acc, part, out_color, loss);
     const bool invd = dL_dinvdepth && loss.kind == 0;
     hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, BWD_REDUCE_SPLIT), dim3(U3D_NACC * U3D_WAVE), 0, s,
-                       d.P, T, invd ? U3D_NACC : U3D_NACC - 1, NG, b.sorted_id, part, acc);
+                       d.P, T, invd ? U3D_NACC : U3D_NACC - 1, NG, b.sorted_id, part, acc, 0, nullptr, 0.f, nullptr);
     return;
   }
   hipLaunchKernelGGL(render_bwd_kernel, dim3(nblocks), dim3(U3D_BLOCK), 0, s, d.P, d.image_height, d.image_width,
