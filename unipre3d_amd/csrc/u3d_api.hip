@@ -13,6 +13,7 @@ namespace {
 // ---- optional per-kernel HIP-event timing (u3d_profile_begin / _end) ---------------------------
 struct ProfRec { hipEvent_t a, b; int kind; };
 bool g_prof_on = false;
+unsigned g_prof_mask = 0xffffffffu;   // kinds to record (bit k = kind k)
 std::vector<ProfRec> g_prof;   // pre-created events
 size_t g_prof_used = 0;
 
@@ -20,7 +21,7 @@ struct ProfScope {
   ProfRec* r = nullptr;
   hipStream_t s;
   ProfScope(int kind, hipStream_t st) : s(st) {
-    if (g_prof_on && g_prof_used < g_prof.size()) {
+    if (g_prof_on && ((g_prof_mask >> kind) & 1u) && g_prof_used < g_prof.size()) {
       r = &g_prof[g_prof_used++];
       r->kind = kind;
       (void)hipEventRecord(r->a, s);
@@ -174,7 +175,7 @@ int u3d_rasterize_forward(const u3d_raster_desc* desc, const float* bg, const fl
       u3d_launch_preprocess_fwd(d, b, plain_source(d, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp),
                                 viewmatrix, projmatrix, campos, radii, nullptr, s);
     }
-    {
+    if (!u3d_preprocess_sorts(d)) {
       ProfScope ps(1, s);
       u3d_launch_depth_sort(d, b, radii, s);
     }
@@ -254,7 +255,7 @@ int u3d_render_loss_forward(const u3d_raster_desc* desc, const u3d_head_desc* he
     u3d_launch_preprocess_fwd(d, b, head_source(d, *head, head_out, center, f.qnorm), viewmatrix, projmatrix, campos, radii,
                               nullptr, s);
   }
-  {
+  if (!u3d_preprocess_sorts(d)) {
     ProfScope ps(1, s);
     u3d_launch_depth_sort(d, b, radii, s);
   }
@@ -335,7 +336,7 @@ int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head,
     ProfScope ps(0, s);
     u3d_launch_preprocess_fwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, s);
   }
-  {
+  if (!u3d_preprocess_sorts(d)) {
     ProfScope ps(1, s);
     u3d_launch_depth_sort(d, b, radii, s);
   }
@@ -368,7 +369,16 @@ int u3d_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
 }
 
 int u3d_profile_begin(int32_t max_records) {
-  if (g_prof_on || max_records <= 0) return U3D_ERR_INVALID_ARGUMENT;
+  if (g_prof_on || max_records == 0) return U3D_ERR_INVALID_ARGUMENT;
+  // negative max_records: -(mask << 20 | records) selects a subset of kinds (each recorded scope costs two event
+  // records on the stream, ~4-5 us of GPU idle; the timed region of bench.py records the dominant kernel only)
+  g_prof_mask = 0xffffffffu;
+  if (max_records < 0) {
+    const unsigned v = (unsigned)(-max_records);
+    g_prof_mask = v >> 20;
+    max_records = (int32_t)(v & 0xfffffu);
+    if (max_records == 0) return U3D_ERR_INVALID_ARGUMENT;
+  }
   g_prof.resize((size_t)max_records);
   for (auto& r : g_prof) {
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return U3D_ERR_NO_DEVICE;

@@ -167,7 +167,11 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     int32_t* __restrict__ radii, float* __restrict__ depth, float2* __restrict__ xy, float4* __restrict__ conic_op,
     float4* __restrict__ rgbd, uint2* __restrict__ rect, uint32_t* __restrict__ clamped,
-    uint32_t* __restrict__ num_rendered, double* __restrict__ acc_zero, size_t NG) {
+    uint32_t* __restrict__ num_rendered, double* __restrict__ acc_zero, size_t NG, uint32_t* __restrict__ sorted_id,
+    uint2* __restrict__ sorted_rect, uint32_t* __restrict__ n_vis) {
+  // (sorted_id != null: P <= 256, the block owns the whole set -> the per-view depth sort is fused in, see below)
+  __shared__ unsigned long long s_keys[U3D_BLOCK];
+  __shared__ uint2 s_rects[U3D_BLOCK];
   // One thread = one Gaussian of set blockIdx.y; it walks the views [v0, v1) of that set, so the view-independent work
   // (head activations, Sigma, SH coefficient fetch) is done once.  blockIdx.z splits the views when P is small.
   extern __shared__ __attribute__((aligned(16))) float s_rec[];   // fused mode: this block's head records, staged coalesced
@@ -211,6 +215,8 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
   for (int vk = v0; vk < v1; ++vk) {
   const int view = item * vpi + vk;
   uint32_t touched = 0;
+  unsigned long long sort_key = ~0ull;
+  uint2 sort_rect = make_uint2(0u, 0u);
   if (i < P) {
     const size_t g = (size_t)view * P + i;
     Cam cam;
@@ -277,6 +283,8 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     rgbd[g] = col;
     rect[g] = rc;
     clamped[g] = cb;
+    if (radius > 0) sort_key = ((unsigned long long)__float_as_uint(zv) << 32) | (uint32_t)i;
+    sort_rect = rc;
     if (acc_zero) {   // single-pass training step: clear this (view, Gaussian)'s gradient accumulators here (saves a memset node)
 #pragma unroll
       for (int k = 0; k < U3D_NACC; ++k) acc_zero[(size_t)k * NG + g] = 0.0;
@@ -287,6 +295,33 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) touched += __shfl_xor(touched, o);
     if ((threadIdx.x & 63) == 0 && touched) atomicAdd(&num_rendered[view], touched);
+  }
+  if (sorted_id) {
+    // fused per-view depth sort (same result as depth_sort_lds_kernel): bitonic network over 256 (depth bits, index) keys
+    const int tid = threadIdx.x;
+    __syncthreads();               // previous view's readers are done with s_keys / s_rects
+    s_keys[tid] = sort_key;
+    s_rects[tid] = sort_rect;
+    __syncthreads();
+    for (int k = 2; k <= U3D_BLOCK; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const int ixj = tid ^ j;
+        if (ixj > tid) {
+          const unsigned long long a = s_keys[tid], b2 = s_keys[ixj];
+          if ((a > b2) == ((tid & k) == 0)) { s_keys[tid] = b2; s_keys[ixj] = a; }
+        }
+        __syncthreads();
+      }
+    }
+    const unsigned long long kk = s_keys[tid];
+    const bool vis = kk != ~0ull;
+    if (tid == 0 && !vis) n_vis[view] = 0;
+    if (vis && (tid == U3D_BLOCK - 1 || s_keys[tid + 1] == ~0ull)) n_vis[view] = (uint32_t)(tid + 1);
+    if (tid < P) {
+      const uint32_t id = vis ? (uint32_t)kk : 0u;
+      sorted_id[(size_t)view * P + tid] = id;
+      sorted_rect[(size_t)view * P + tid] = vis ? s_rects[id] : make_uint2(0u, 0u);
+    }
   }
   }
 }
@@ -636,8 +671,11 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 
 }  // namespace
 
+bool u3d_preprocess_sorts(const u3d_raster_desc& d) { return d.P <= U3D_BLOCK; }
+
 void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, int32_t* radii, double* acc_zero, hipStream_t s) {
+  const bool fuse_sort = u3d_preprocess_sorts(d);
   const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
   // enough Gaussians to fill the chip by themselves -> one thread walks all views of its set; otherwise split the views
   const int vpt = ((size_t)d.P * d.n_items >= 65536) ? d.views_per_item : 1;
@@ -648,7 +686,8 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 #define LAUNCH(DEG)                                                                                                   \
   hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, lds, s, d.P, d.views_per_item, vpt, d.image_height,     \
                      d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, src, viewmatrix, projmatrix, campos, \
-                     radii, b.depth, b.xy, b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered, acc_zero, NG)
+                     radii, b.depth, b.xy, b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered, acc_zero, NG,               \
+                     fuse_sort ? b.sorted_id : nullptr, b.sorted_rect, b.n_vis)
   switch (D) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;
