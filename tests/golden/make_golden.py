@@ -13,6 +13,7 @@ that fix the operator's conventions and inputs:
   G4 render losses + seeds      utils/loss_utils.py:17-45
   G5 SH polynomials             utils/sh_utils.py:57-116
   G6 projection / covariance    utils/graphics_utils.py:22-30, utils/general_utils.py:171-206
+  G7 2D->3D feature fusion      fusion/feat_fusion.py:23-145 (projection, z-buffer, gather; output and gradient)
 """
 import importlib.util
 import math
@@ -227,8 +228,43 @@ def g6_geometry():
         torch.zeros = oz
 
 
+def g7_feature_fusion():
+    """fusion/feat_fusion.py (pure torch) run as is on the CPU: output + gradient w.r.t. the image features."""
+    spec = importlib.util.spec_from_file_location("ref_feat_fusion", os.path.join(REF, "fusion/feat_fusion.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    for tag, (B, N, Cx, C, H, W, cls) in {"sq": (2, 64, 8, 6, 16, 16, True), "rect": (3, 40, 4, 5, 12, 20, False)}.items():
+        g = torch.Generator().manual_seed(17 + H)
+        center = torch.randn(B, N, 3, generator=g) * 0.4
+        center[:, 5] = center[:, 4]                       # exact duplicate -> depth tie at one pixel
+        center[:, 9, 2] = -5.0                            # behind the camera
+        center[:, 11, 0] = 30.0                           # projects outside the image
+        # row-vector view->world matrices like dataset/shapenet.py:311-313 (transpose of a rigid transform)
+        A = torch.eye(3).repeat(B, 1, 1) + 0.15 * torch.randn(B, 3, 3, generator=g)   # camera looks roughly along +z
+        Q, Rr = torch.linalg.qr(A)
+        Q = Q * torch.sign(torch.diagonal(Rr, dim1=1, dim2=2)).unsqueeze(1)
+        c2w = torch.eye(4).repeat(B, 1, 1)
+        c2w[:, :3, :3] = Q
+        c2w[:, :3, 3] = torch.tensor([0.0, 0.0, -2.0]) + 0.1 * torch.randn(B, 3, generator=g)
+        c2w_rowvec = c2w.transpose(1, 2).contiguous()
+        focal = (H / 2.0) / math.tan(math.radians(49.13434264120263 / 2.0))
+        intr = np.zeros((3, 4)); intr[2, 2] = 1; intr[0, 0] = intr[1, 1] = focal; intr[0, 2] = H / 2.0; intr[1, 2] = W / 2.0
+        feat = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+        x = torch.randn(B, N + (1 if cls else 0), Cx, generator=g)
+        ff = mod.FeatureFusion(torch.nn.Identity())
+        y = ff(x, center, feat, c2w_rowvec, intr)
+        w = torch.randn(y.shape, generator=g)
+        (gfeat,) = torch.autograd.grad((y * w).sum(), feat)
+        pi_xy, depth = ff.project_points_to_image(center, c2w_rowvec, intr)
+        out.update({f"{tag}_x": x.numpy(), f"{tag}_center": center.numpy(), f"{tag}_c2w": c2w_rowvec.numpy(), f"{tag}_intr": intr,
+                    f"{tag}_feat": feat.detach().numpy(), f"{tag}_out": y.detach().numpy(), f"{tag}_w": w.numpy(),
+                    f"{tag}_gfeat": gfeat.numpy(), f"{tag}_pix": pi_xy.numpy(), f"{tag}_depth": depth.numpy()})
+    np.savez(os.path.join(OUT, "g7_feature_fusion.npz"), **out)
+
+
 if __name__ == "__main__":
-    g1_cameras(); g5_sh(); g4_losses(); g6_geometry(); g2_head(); g3_boundary()
+    g1_cameras(); g5_sh(); g4_losses(); g6_geometry(); g7_feature_fusion(); g2_head(); g3_boundary()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -43,3 +43,31 @@ def test_single_process_helpers():
     h = dp.GaussianHead()
     assert h(torch.zeros(2, 128, 384)).shape == (2, 23, 128)
     assert sum(p.numel() for p in h.parameters()) == 384 * 128 + 128 + 128 * 23 + 23   # 52,247
+
+
+def test_check_and_clip_gradients_matches_reference_semantics():
+    """train_network.py:368-390: False on any NaN/Inf (grads untouched), else clip_grad_norm_(max_norm=1.0)."""
+    from unipre3d_amd.gradcheck import check_and_clip_gradients
+    torch.manual_seed(0)
+    m1, m2 = torch.nn.Linear(7, 5), torch.nn.Linear(7, 5)
+    m2.load_state_dict(m1.state_dict())
+    x = torch.randn(9, 7)
+    for m in (m1, m2):
+        (m(x) ** 2).sum().mul(10).backward()
+    assert check_and_clip_gradients(m1.parameters(), 1.0)
+    has_invalid = any(torch.isnan(p.grad).any() or torch.isinf(p.grad).any() for p in m2.parameters())
+    assert not has_invalid
+    torch.nn.utils.clip_grad_norm_(m2.parameters(), max_norm=1.0)
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-8)
+    total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m1.parameters()))
+    assert abs(total.item() - 1.0) < 1e-4                                # it was above the threshold and got clipped
+    # small gradients are left alone
+    m1.zero_grad(); (m1(x).sum() * 1e-4).backward(); g0 = [p.grad.clone() for p in m1.parameters()]
+    assert check_and_clip_gradients(m1.parameters(), 1.0) and all(torch.equal(a, p.grad) for a, p in zip(g0, m1.parameters()))
+    # any non-finite entry -> False and the step is to be skipped
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        m1.weight.grad[2, 3] = bad
+        assert not check_and_clip_gradients(m1.parameters(), 1.0)
+        m1.weight.grad[2, 3] = 0.0
+    assert check_and_clip_gradients([torch.nn.Parameter(torch.zeros(3))], 1.0)   # no .grad at all

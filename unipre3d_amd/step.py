@@ -52,6 +52,9 @@ def train_step(model: torch.nn.Module, feats: torch.Tensor, batch: SyntheticBatc
         loss, _ = render_loss_forward(raw, batch, H, W, input_images, loss_kind, render_fn)
     loss.backward()
     if clip_grad is not None:
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip_grad)
+        from .gradcheck import check_and_clip_gradients
+        if not check_and_clip_gradients(model.parameters(), clip_grad):   # NaN/Inf: skip the step (train_network.py:336-340)
+            optimizer.zero_grad(set_to_none=True)
+            return loss.detach()
     optimizer.step()
     return loss.detach()
