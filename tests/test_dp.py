@@ -71,3 +71,17 @@ def test_check_and_clip_gradients_matches_reference_semantics():
         assert not check_and_clip_gradients(m1.parameters(), 1.0)
         m1.weight.grad[2, 3] = 0.0
     assert check_and_clip_gradients([torch.nn.Parameter(torch.zeros(3))], 1.0)   # no .grad at all
+
+
+def test_standin_predictor_has_the_reference_parameter_counts():
+    """encoder 29,066,880 + final 52,247 + fusion Linear 295,296 + image 1x1 conv/GN 49,792 = 117.9 MB fp32."""
+    from unipre3d_amd.standin import PointTransformerStandIn, object_intrinsics
+    m = PointTransformerStandIn()
+    assert m.encoder_parameters() == 29_066_880
+    assert sum(p.numel() for p in m.final.parameters()) == 52_247
+    assert sum(p.numel() for p in m.fusion_mlps.parameters()) == 295_296
+    assert sum(p.numel() for p in m.image_conv.parameters()) == 49_792
+    total = sum(p.numel() for p in m.parameters())
+    assert total == 29_464_215 and abs(total * 4 / 1e6 - 117.9) < 0.1
+    k = object_intrinsics(49.13434264120263, 128)
+    assert abs(k[0, 0] - 140.0) < 1e-3 and k[0, 2] == 64.0                 # fx = fy = 140, cx = cy = 64 (SURVEY 8c)
