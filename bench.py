@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     a = ap.parse_args()
 
-    rank, local_rank, world = dp.init_from_env()
+    rank, local_rank, world = dp.init_from_env(os.environ.get("U3D_BENCH_BACKEND"))   # default: nccl (= RCCL) on GPUs
     if world != a.gpus:
         if rank == 0:
             print(f"[bench] WORLD_SIZE={world} but --gpus {a.gpus}; using WORLD_SIZE", file=sys.stderr)
