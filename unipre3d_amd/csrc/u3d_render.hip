@@ -222,7 +222,8 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_bwd_wave_kerne
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
     float T_final[4], Tr[4], dp0[4], dp1[4], dp2[4], dinv[4], bg_dot[4], pyf[4];
-    float ar0[4], ar1[4], ar2[4], lc0[4], lc1[4], lc2[4], last_alpha[4], ainv[4], linv[4];
+    // "behind" recurrences  a <- la*l + (1-la)*a  kept as  a <- fma(oml, a, u)  with u = la*l, oml = 1-la
+    float ar0[4], ar1[4], ar2[4], u0[4], u1[4], u2[4], oml[4], tfb[4], ainv[4], uinv[4];
     uint32_t last[4];
     uint32_t wmax = 0;
 #pragma unroll
@@ -257,7 +258,9 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_bwd_wave_kerne
       }
       bg_dot[k] = bg[0] * dp0[k] + bg[1] * dp1[k] + bg[2] * dp2[k];
       Tr[k] = T_final[k];
-      ar0[k] = ar1[k] = ar2[k] = lc0[k] = lc1[k] = lc2[k] = last_alpha[k] = ainv[k] = linv[k] = 0.f;
+      ar0[k] = ar1[k] = ar2[k] = u0[k] = u1[k] = u2[k] = ainv[k] = uinv[k] = 0.f;
+      oml[k] = 1.f;
+      tfb[k] = T_final[k] * bg_dot[k];
       wmax = max(wmax, last[k]);
     }
 #pragma unroll
@@ -302,23 +305,22 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_bwd_wave_kerne
           const bool ok = pos <= last[k] && pw <= 0.f && alpha >= ALPHA_MIN;
           if (ok) {
             any = true;
-            const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
+            const float om = 1.f - alpha;
+            const float rc = __builtin_amdgcn_rcpf(om);
             Tr[k] = Tr[k] * rc;
             const float w = alpha * Tr[k];
-            const float la = last_alpha[k];
-            ar0[k] = la * lc0[k] + (1.f - la) * ar0[k]; lc0[k] = Cc.x;
-            ar1[k] = la * lc1[k] + (1.f - la) * ar1[k]; lc1[k] = Cc.y;
-            ar2[k] = la * lc2[k] + (1.f - la) * ar2[k]; lc2[k] = Cc.z;
+            ar0[k] = fmaf(oml[k], ar0[k], u0[k]); u0[k] = alpha * Cc.x;
+            ar1[k] = fmaf(oml[k], ar1[k], u1[k]); u1[k] = alpha * Cc.y;
+            ar2[k] = fmaf(oml[k], ar2[k], u2[k]); u2[k] = alpha * Cc.z;
             float dL_dalpha = (Cc.x - ar0[k]) * dp0[k] + (Cc.y - ar1[k]) * dp1[k] + (Cc.z - ar2[k]) * dp2[k];
             g_r = fmaf(w, dp0[k], g_r); g_g = fmaf(w, dp1[k], g_g); g_b = fmaf(w, dp2[k], g_b);
             if (HAS_INVD) {
-              ainv[k] = la * linv[k] + (1.f - la) * ainv[k]; linv[k] = B.z;
+              ainv[k] = fmaf(oml[k], ainv[k], uinv[k]); uinv[k] = alpha * B.z;
               dL_dalpha += (B.z - ainv[k]) * dinv[k];
               g_d = fmaf(w, dinv[k], g_d);
             }
-            dL_dalpha *= Tr[k];
-            last_alpha[k] = alpha;
-            dL_dalpha += (-T_final[k] * rc) * bg_dot[k];
+            oml[k] = om;
+            dL_dalpha = fmaf(dL_dalpha, Tr[k], -(tfb[k] * rc));
             const float q = B.y * dL_dalpha * G;    // dL/dG * G
             const float qdx = q * dx, qdy = q * dy;
             m0 += q; mx += qdx; my += qdy;
@@ -539,11 +541,14 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
   if (lane == 0) loss.partial[lid] = e;
 
   // ---------------- backward ----------------
-  float ar0[4], ar1[4], ar2[4], lc0[4], lc1[4], lc2[4], last_alpha[4];
+  // "colour behind" recurrence  ar <- la*lc + (1-la)*ar  kept as  ar <- fma(oml, ar, u)  with u = la*lc, oml = 1-la
+  float ar0[4], ar1[4], ar2[4], u0[4], u1[4], u2[4], oml[4], tfb[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     Tr[k] = T_final[k];
-    ar0[k] = ar1[k] = ar2[k] = lc0[k] = lc1[k] = lc2[k] = last_alpha[k] = 0.f;
+    ar0[k] = ar1[k] = ar2[k] = u0[k] = u1[k] = u2[k] = 0.f;
+    oml[k] = 1.f;
+    tfb[k] = T_final[k] * bg_dot[k];
   }
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
   const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
@@ -571,18 +576,17 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
         const bool ok = pos <= last[k] && pw <= 0.f && alpha >= ALPHA_MIN;
         if (ok) {
           any = true;
-          const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
+          const float om = 1.f - alpha;
+          const float rc = __builtin_amdgcn_rcpf(om);
           Tr[k] = Tr[k] * rc;
           const float w = alpha * Tr[k];
-          const float la = last_alpha[k];
-          ar0[k] = la * lc0[k] + (1.f - la) * ar0[k]; lc0[k] = Cc.x;
-          ar1[k] = la * lc1[k] + (1.f - la) * ar1[k]; lc1[k] = Cc.y;
-          ar2[k] = la * lc2[k] + (1.f - la) * ar2[k]; lc2[k] = Cc.z;
+          ar0[k] = fmaf(oml[k], ar0[k], u0[k]); u0[k] = alpha * Cc.x;
+          ar1[k] = fmaf(oml[k], ar1[k], u1[k]); u1[k] = alpha * Cc.y;
+          ar2[k] = fmaf(oml[k], ar2[k], u2[k]); u2[k] = alpha * Cc.z;
+          oml[k] = om;
           float dL_dalpha = (Cc.x - ar0[k]) * dp0[k] + (Cc.y - ar1[k]) * dp1[k] + (Cc.z - ar2[k]) * dp2[k];
           g_r = fmaf(w, dp0[k], g_r); g_g = fmaf(w, dp1[k], g_g); g_b = fmaf(w, dp2[k], g_b);
-          dL_dalpha *= Tr[k];
-          last_alpha[k] = alpha;
-          dL_dalpha += (-T_final[k] * rc) * bg_dot[k];
+          dL_dalpha = fmaf(dL_dalpha, Tr[k], -(tfb[k] * rc));
           const float q = B.y * dL_dalpha * G;
           const float qdx = q * dx, qdy = q * dy;
           m0 += q; mx += qdx; my += qdy;
