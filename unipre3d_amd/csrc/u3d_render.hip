@@ -170,6 +170,22 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
+// Per-Gaussian gradient rows travel as RAW moments (mx, my, mxx, mxy, myy, m0, r, g, b, d); they are linear in the pixels, so
+// the conversion to accumulator values (which needs the Gaussian's own conic / opacity) is applied once after summation:
+//   dL/dmean2D = -(W/2, H/2) * (a mx + b my, c my + b mx),  dL/dconic = -1/2 (mxx, mxy, myy),  dL/dopacity = m0 / opacity.
+template <typename T>
+__device__ __forceinline__ T moment_to_acc(int k, const T* m, float a, float b, float c, float op, float half_w, float half_h) {
+  switch (k) {
+    case 0: return -(T)half_w * ((T)a * m[0] + (T)b * m[1]);
+    case 1: return -(T)half_h * ((T)c * m[1] + (T)b * m[0]);
+    case 2: return (T)-0.5 * m[2];
+    case 3: return (T)-0.5 * m[3];
+    case 4: return (T)-0.5 * m[4];
+    case 5: return m[5] != (T)0 ? m[5] / (T)op : (T)0;
+    default: return m[k];
+  }
+}
+
 // ---- backward, wave-per-tile form --------------------------------------------------------------
 // One WAVE owns one 16x16 tile (4 pixels per lane: column lane&15, rows (lane>>4) + 4k); a workgroup is
 // BWD_WAVES independent tiles: the batch loop has no workgroup barrier, LDS regions are wave-private.  Per
@@ -201,14 +217,14 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_bwd_wave_kerne
   __shared__ float4 sA[BWD_WAVES][U3D_WAVE];   // x, y, a, b
   __shared__ float4 sB[BWD_WAVES][U3D_WAVE];   // c, opacity, 1/depth, pos (bits)
   __shared__ float4 sC[BWD_WAVES][U3D_WAVE];   // r, g, b, id (bits)
-  __shared__ float sAcc[BWD_WAVES][U3D_NACC][U3D_WAVE];
+  __shared__ float4 sAcc[BWD_WAVES][U3D_WAVE][3];   // per slot: {mx,my,mxx,mxy} {myy,m0,r,g} {b,d,-,-}
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t lid = u3d_xcd_remap(blockIdx.x, nblocks) * (uint32_t)BWD_WAVES + (uint32_t)wave;
   if (lid >= ntiles_total) return;   // whole wave leaves; there is no workgroup barrier below
   const int view = (int)(lid / T);
 #pragma unroll
-  for (int k = 0; k < NK; ++k) sAcc[wave][k][lane] = 0.f;
+  for (int k = 0; k < 3; ++k) sAcc[wave][lane][k] = make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t wmax_all = 0;
 
   {
@@ -350,14 +366,9 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_bwd_wave_kerne
         if (lane == 63) {
           // batch 0 is indexed by sorted position (merged across tiles below), later batches by compaction slot
           const int slot = b == 0 ? (int)pos - 1 : j;
-          sAcc[wave][0][slot] = -ddelx_dx * (A.z * mx + A.w * my);
-          sAcc[wave][1][slot] = -ddely_dy * (B.x * my + A.w * mx);
-          sAcc[wave][2][slot] = -0.5f * mxx;
-          sAcc[wave][3][slot] = -0.5f * mxy;
-          sAcc[wave][4][slot] = -0.5f * myy;
-          sAcc[wave][5][slot] = m0 / B.y;
-          sAcc[wave][6][slot] = g_r; sAcc[wave][7][slot] = g_g; sAcc[wave][8][slot] = g_b;
-          if (HAS_INVD) sAcc[wave][9][slot] = g_d;
+          sAcc[wave][slot][0] = make_float4(mx, my, mxx, mxy);
+          sAcc[wave][slot][1] = make_float4(myy, m0, g_r, g_g);
+          sAcc[wave][slot][2] = make_float4(g_b, g_d, 0.f, 0.f);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -365,14 +376,17 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_bwd_wave_kerne
       if (b > 0) {
         if (lane < total) {
           const size_t g = vbase + __float_as_uint(sC[wave][lane].w);
+          const float4 m0v = sAcc[wave][lane][0], m1v = sAcc[wave][lane][1], m2v = sAcc[wave][lane][2];
+          const float4 Ag = sA[wave][lane], Bg = sB[wave][lane];
+          const float m[U3D_NACC] = {m0v.x, m0v.y, m0v.z, m0v.w, m1v.x, m1v.y, m1v.z, m1v.w, m2v.x, m2v.y};
 #pragma unroll
           for (int k = 0; k < NK; ++k) {
-            const float v = sAcc[wave][k][lane];
+            const float v = moment_to_acc<float>(k, m, Ag.z, Ag.w, Bg.x, Bg.y, ddelx_dx, ddely_dy);
             if (v != 0.f) unsafeAtomicAdd(&acc[(size_t)k * NG + g], (double)v);
           }
         }
 #pragma unroll
-        for (int k = 0; k < NK; ++k) sAcc[wave][k][lane] = 0.f;
+        for (int k = 0; k < 3; ++k) sAcc[wave][lane][k] = make_float4(0.f, 0.f, 0.f, 0.f);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
@@ -386,7 +400,7 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_bwd_wave_kerne
   const uint32_t cnt = min(wmax_all, (uint32_t)U3D_WAVE);
   if ((uint32_t)lane < cnt) {
 #pragma unroll
-    for (int k = 0; k < NK; ++k) pt[k * U3D_WAVE + lane] = sAcc[wave][k][lane];
+    for (int k = 0; k < NK; ++k) pt[k * U3D_WAVE + lane] = reinterpret_cast<const float*>(&sAcc[wave][lane][0])[k];   // raw moments
   }
   if (lane == 0) reinterpret_cast<uint32_t*>(pt)[U3D_NACC * U3D_WAVE] = cnt;
 }
@@ -407,7 +421,7 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
   __shared__ float4 sA[BWD_WAVES][U3D_WAVE];   // x, y, a, b
   __shared__ float4 sB[BWD_WAVES][U3D_WAVE];   // c, opacity, 1/depth, pos (bits)
   __shared__ float4 sC[BWD_WAVES][U3D_WAVE];   // r, g, b, id (bits)
-  __shared__ float sAcc[BWD_WAVES][U3D_NACC][U3D_WAVE];
+  __shared__ float4 sAcc[BWD_WAVES][U3D_WAVE][3];   // per slot: {mx,my,mxx,mxy} {myy,m0,r,g} {b,d,-,-}
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t lid = u3d_xcd_remap(blockIdx.x, nblocks) * (uint32_t)BWD_WAVES + (uint32_t)wave;
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
   const size_t npix = (size_t)H * W;
   const uint32_t nv = n_vis[view];
 #pragma unroll
-  for (int k = 0; k < NK; ++k) sAcc[wave][k][lane] = 0.f;
+  for (int k = 0; k < 3; ++k) sAcc[wave][lane][k] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // stage sorted entries [b*64, b*64+64) limited to `limit`; returns the hit ballot
   auto stage = [&](int b, uint32_t limit) -> unsigned long long {
@@ -611,13 +625,9 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
 #undef U3D_DPP9
       if (lane == 63) {
         const int slot = b == 0 ? (int)pos - 1 : j;
-        sAcc[wave][0][slot] = -ddelx_dx * (A.z * mx + A.w * my);
-        sAcc[wave][1][slot] = -ddely_dy * (B.x * my + A.w * mx);
-        sAcc[wave][2][slot] = -0.5f * mxx;
-        sAcc[wave][3][slot] = -0.5f * mxy;
-        sAcc[wave][4][slot] = -0.5f * myy;
-        sAcc[wave][5][slot] = m0 / B.y;
-        sAcc[wave][6][slot] = g_r; sAcc[wave][7][slot] = g_g; sAcc[wave][8][slot] = g_b;
+        sAcc[wave][slot][0] = make_float4(mx, my, mxx, mxy);
+        sAcc[wave][slot][1] = make_float4(myy, m0, g_r, g_g);
+        sAcc[wave][slot][2] = make_float4(g_b, 0.f, 0.f, 0.f);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -625,14 +635,17 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
     if (b > 0) {
       if (lane < total) {
         const size_t g = vbase + __float_as_uint(sC[wave][lane].w);
+        const float4 m0v = sAcc[wave][lane][0], m1v = sAcc[wave][lane][1], m2v = sAcc[wave][lane][2];
+        const float4 Ag = sA[wave][lane], Bg = sB[wave][lane];
+        const float m[U3D_NACC] = {m0v.x, m0v.y, m0v.z, m0v.w, m1v.x, m1v.y, m1v.z, m1v.w, m2v.x, m2v.y};
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-          const float v = sAcc[wave][k][lane];
+          const float v = moment_to_acc<float>(k, m, Ag.z, Ag.w, Bg.x, Bg.y, ddelx_dx, ddely_dy);
           if (v != 0.f) unsafeAtomicAdd(&acc[(size_t)k * NG + g], (double)v);
         }
       }
 #pragma unroll
-      for (int k = 0; k < NK; ++k) sAcc[wave][k][lane] = 0.f;
+      for (int k = 0; k < 3; ++k) sAcc[wave][lane][k] = make_float4(0.f, 0.f, 0.f, 0.f);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
@@ -641,23 +654,25 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
   const uint32_t cnt = min(wmax, (uint32_t)U3D_WAVE);
   if ((uint32_t)lane < cnt) {
 #pragma unroll
-    for (int k = 0; k < NK; ++k) pt[k * U3D_WAVE + lane] = sAcc[wave][k][lane];
+    for (int k = 0; k < NK; ++k) pt[k * U3D_WAVE + lane] = reinterpret_cast<const float*>(&sAcc[wave][lane][0])[k];   // raw moments
   }
   if (lane == 0) reinterpret_cast<uint32_t*>(pt)[U3D_NACC * U3D_WAVE] = cnt;
 }
 
 // acc[k][view*P + sorted_id[sp]] += sum over a slice of the view's tiles (ascending) of part[tile][k][sp], in f64;
 // the BWD_REDUCE_SPLIT slices of a view meet in an f64 atomic (order-insensitive at fp32 output precision).
-__global__ __launch_bounds__(U3D_NACC * U3D_WAVE) void bwd_reduce_kernel(int P, int T, int NK, size_t NG,
+__global__ __launch_bounds__(U3D_NACC * U3D_WAVE) void bwd_reduce_kernel(int P, int T, int NK, size_t NG, float half_w, float half_h,
                                                                         const uint32_t* __restrict__ sorted_id,
+                                                                        const float4* __restrict__ conic_op,
                                                                         const float* __restrict__ part,
                                                                         double* __restrict__ acc, int n_loss,
                                                                         const float* __restrict__ loss_partial, float inv_count,
                                                                         float* __restrict__ loss_out) {
+  __shared__ double s_sum[U3D_NACC][U3D_WAVE];
   if (blockIdx.y == BWD_REDUCE_SPLIT) {
     // extra row of the grid: fixed-order sum of the per-tile loss partials (replaces a separate launch)
     if (blockIdx.x != 0) return;
-    __shared__ float sm[U3D_NACC * U3D_WAVE];
+    float* sm = reinterpret_cast<float*>(&s_sum[0][0]);
     constexpr int NT = U3D_NACC * U3D_WAVE;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int i = threadIdx.x;
@@ -677,37 +692,53 @@ __global__ __launch_bounds__(U3D_NACC * U3D_WAVE) void bwd_reduce_kernel(int P, 
     return;
   }
   const int view = blockIdx.x, k = threadIdx.x >> 6, sp = threadIdx.x & 63;
+  double a = 0.0;
+  if (k < NK) {
+    const int per = (T + BWD_REDUCE_SPLIT - 1) / BWD_REDUCE_SPLIT;
+    const int t0 = blockIdx.y * per, t1 = min(T, t0 + per);
+    const float* base = part + (size_t)view * T * BWD_PART_STRIDE;
+    // loads are unconditional (rows a tile did not write hold stale bytes, discarded by the select) so that a whole group
+    // of tiles is in flight at once; accumulation order stays ascending in t within each of the two chains
+    double a0 = 0.0, a1 = 0.0;
+    int t = t0;
+    for (; t + 7 < t1; t += 8) {
+      float v[8];
+      uint32_t c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* pu = base + (size_t)(t + u) * BWD_PART_STRIDE;
+        c[u] = reinterpret_cast<const uint32_t*>(pu)[U3D_NACC * U3D_WAVE];
+        v[u] = pu[k * U3D_WAVE + sp];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        a0 += (uint32_t)sp < c[u] ? (double)v[u] : 0.0;
+        a1 += (uint32_t)sp < c[u + 1] ? (double)v[u + 1] : 0.0;
+      }
+    }
+    for (; t < t1; ++t) {
+      const float* p0 = base + (size_t)t * BWD_PART_STRIDE;
+      const uint32_t c0 = reinterpret_cast<const uint32_t*>(p0)[U3D_NACC * U3D_WAVE];
+      const float v0 = p0[k * U3D_WAVE + sp];
+      a0 += (uint32_t)sp < c0 ? (double)v0 : 0.0;
+    }
+    a = a0 + a1;
+  }
+  // raw moment sums of this slice -> accumulator values (linear, so slices can be converted independently)
+  s_sum[k][sp] = a;
+  __syncthreads();
   if (k >= NK) return;
-  const int per = (T + BWD_REDUCE_SPLIT - 1) / BWD_REDUCE_SPLIT;
-  const int t0 = blockIdx.y * per, t1 = min(T, t0 + per);
-  const float* base = part + (size_t)view * T * BWD_PART_STRIDE;
-  // loads are unconditional (rows a tile did not write hold stale bytes, discarded by the select) so that a whole group
-  // of tiles is in flight at once; accumulation order stays ascending in t within each of the two chains
-  double a0 = 0.0, a1 = 0.0;
-  int t = t0;
-  for (; t + 7 < t1; t += 8) {
-    float v[8];
-    uint32_t c[8];
+  double m[U3D_NACC];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float* pu = base + (size_t)(t + u) * BWD_PART_STRIDE;
-      c[u] = reinterpret_cast<const uint32_t*>(pu)[U3D_NACC * U3D_WAVE];
-      v[u] = pu[k * U3D_WAVE + sp];
-    }
+  for (int j = 0; j < U3D_NACC; ++j) m[j] = j < NK ? s_sum[j][sp] : 0.0;
+  bool any = false;
 #pragma unroll
-    for (int u = 0; u < 8; u += 2) {
-      a0 += (uint32_t)sp < c[u] ? (double)v[u] : 0.0;
-      a1 += (uint32_t)sp < c[u + 1] ? (double)v[u + 1] : 0.0;
-    }
-  }
-  for (; t < t1; ++t) {
-    const float* p0 = base + (size_t)t * BWD_PART_STRIDE;
-    const uint32_t c0 = reinterpret_cast<const uint32_t*>(p0)[U3D_NACC * U3D_WAVE];
-    const float v0 = p0[k * U3D_WAVE + sp];
-    a0 += (uint32_t)sp < c0 ? (double)v0 : 0.0;
-  }
-  const double a = a0 + a1;
-  if (a != 0.0) unsafeAtomicAdd(&acc[(size_t)k * NG + (size_t)view * P + sorted_id[(size_t)view * P + sp]], a);
+  for (int j = 0; j < U3D_NACC; ++j) any = any || m[j] != 0.0;
+  if (!any) return;
+  const size_t g = (size_t)view * P + sorted_id[(size_t)view * P + sp];
+  const float4 co = conic_op[g];
+  const double outv = moment_to_acc<double>(k, m, co.x, co.y, co.z, co.w, half_w, half_h);
+  if (outv != 0.0) unsafeAtomicAdd(&acc[(size_t)k * NG + g], outv);
 }
 
 // Fixed-order sum of the per-tile partials (deterministic): 1024 threads, 4 independent accumulators each.
@@ -760,7 +791,8 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
                      tiles_x, T, nblocks, nwg, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
                      acc, part, loss);
   hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, BWD_REDUCE_SPLIT + 1), dim3(U3D_NACC * U3D_WAVE), 0, s,
-                     d.P, T, U3D_NACC - 1, NG, b.sorted_id, part, acc, (int)nblocks, loss.partial, loss.inv_count, loss_out);
+                     d.P, T, U3D_NACC - 1, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id, b.conic_op, part,
+                     acc, (int)nblocks, loss.partial, loss.inv_count, loss_out);
 }
 
 void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, const float* dL_dcolor,
@@ -782,6 +814,7 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
                        tiles_x, T, nblocks, nwg, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg, dL_dcolor,
                        dL_dinvdepth, b.final_T, b.n_contrib, acc, part, out_color, loss);
   hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, BWD_REDUCE_SPLIT), dim3(U3D_NACC * U3D_WAVE), 0, s,
-                     d.P, T, invd ? U3D_NACC : U3D_NACC - 1, NG, b.sorted_id, part, acc, 0, nullptr, 0.f, nullptr);
+                     d.P, T, invd ? U3D_NACC : U3D_NACC - 1, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id,
+                     b.conic_op, part, acc, 0, nullptr, 0.f, nullptr);
 
 }
