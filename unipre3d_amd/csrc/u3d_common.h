@@ -10,6 +10,9 @@
 #define U3D_WAVE 64
 #define U3D_NACC 10         // mean2D.xy, conic(a, b/2, c), opacity, rgb, invdepth
 #define U3D_LDS_SORT_MAX 4096  // largest per-view P sorted by one workgroup in LDS
+// keys per workgroup and radix pass (P > U3D_LDS_SORT_MAX): small tiles keep more workgroups in flight (the passes are
+// latency-bound), large tiles keep the per-block offset scan short
+static inline int u3d_radix_tile(int P) { return P <= 65536 ? 1024 : 4096; }
 
 // Per-call view of the carved scratch buffers (device pointers; built on the host).
 struct U3DBuffers {
@@ -126,7 +129,7 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
     CARVE(bn, sort_keys[1], uint32_t, NG);
     CARVE(bn, sort_vals[0], uint32_t, NG);
     CARVE(bn, sort_vals[1], uint32_t, NG);
-    const size_t nblk = ((size_t)d.P + 4095) / 4096;
+    const size_t nblk = ((size_t)d.P + u3d_radix_tile(d.P) - 1) / u3d_radix_tile(d.P);
     CARVE(bn, sort_hist, uint32_t, NV * 256 * nblk);
   } else if (b) {
     b->sort_keys[0] = b->sort_keys[1] = b->sort_vals[0] = b->sort_vals[1] = b->sort_hist = nullptr;

@@ -10,7 +10,9 @@
 //  * P <= 4096: one workgroup per view, bitonic network on 64-bit keys (depth bits << 32 | index)
 //    entirely in LDS (32 KiB of the CU's 160 KiB).
 //  * larger P: 4-pass LSD radix sort (8-bit digits) on the depth bits with the index as payload;
-//    LSD passes are stable and the initial order is index order, so ties resolve by index.
+//    LSD passes are stable and the initial order is index order, so ties resolve by index.  Per pass: per-block digit
+//    histogram, then a scatter whose prologue turns the histograms into its own offsets (no separate scan launch) and
+//    ranks keys with ballot multi-split (8 ballots per key, stable within the wave, waves ordered through LDS).
 #include "u3d_common.h"
 
 namespace {
@@ -56,9 +58,7 @@ __global__ __launch_bounds__(1024) void depth_sort_lds_kernel(int P, int N, cons
   }
 }
 
-// ---- large P: LSD radix sort, 8-bit digits, 4096 keys per workgroup ---------------------------
-constexpr int RADIX_ITEMS = 16;               // keys per thread
-constexpr int RADIX_TILE = U3D_BLOCK * RADIX_ITEMS;  // 4096
+// ---- large P: LSD radix sort, 8-bit digits, ITEMS*256 keys per workgroup (u3d_radix_tile) -------
 
 __device__ __forceinline__ uint32_t radix_key(int pass, int P, int idx, size_t base, const float* depth,
                                               const int32_t* radii, const uint32_t* keys_in) {
@@ -66,6 +66,7 @@ __device__ __forceinline__ uint32_t radix_key(int pass, int P, int idx, size_t b
   return keys_in[base + idx];
 }
 
+template <int RADIX_ITEMS>
 __global__ __launch_bounds__(U3D_BLOCK) void radix_hist_kernel(int pass, int P, int nblk, const float* __restrict__ depth,
                                                                const int32_t* __restrict__ radii,
                                                                const uint32_t* __restrict__ keys_in,
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void radix_hist_kernel(int pass, int P, 
   __syncthreads();
 #pragma unroll 4
   for (int r = 0; r < RADIX_ITEMS; ++r) {
-    const int idx = blk * RADIX_TILE + r * U3D_BLOCK + threadIdx.x;
+    const int idx = blk * (RADIX_ITEMS * U3D_BLOCK) + r * U3D_BLOCK + threadIdx.x;
     if (idx < P) {
       const uint32_t k = radix_key(pass, P, idx, base, depth, radii, keys_in);
       atomicAdd(&h[(k >> (8 * pass)) & 255u], 1u);
@@ -87,44 +88,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void radix_hist_kernel(int pass, int P, 
   hist[((size_t)view * nblk + blk) * 256 + threadIdx.x] = h[threadIdx.x];   // [view][block][digit]: coalesced
 }
 
-// hist[view][blk][digit] (counts) -> global exclusive offsets in (digit-major, block-minor) order, in place.
-// One workgroup per view, thread = digit; both sweeps read coalesced rows whose loads do not depend on the running sum.
-__global__ __launch_bounds__(U3D_BLOCK) void radix_scan_kernel(int nblk, uint32_t* __restrict__ hist) {
-  __shared__ uint32_t tot[256];
-  const int view = blockIdx.x, d = threadIdx.x;
-  uint32_t* col = hist + (size_t)view * nblk * 256 + d;
-  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int b = 0;
-  for (; b + 3 < nblk; b += 4) {
-    s0 += col[(size_t)b * 256]; s1 += col[(size_t)(b + 1) * 256]; s2 += col[(size_t)(b + 2) * 256]; s3 += col[(size_t)(b + 3) * 256];
-  }
-  for (; b < nblk; ++b) s0 += col[(size_t)b * 256];
-  const uint32_t s = (s0 + s1) + (s2 + s3);
-  tot[d] = s;
-  __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) {
-    const uint32_t v = d >= o ? tot[d - o] : 0u;
-    __syncthreads();
-    tot[d] += v;
-    __syncthreads();
-  }
-  uint32_t off = tot[d] - s;
-  b = 0;
-  for (; b + 3 < nblk; b += 4) {
-    const uint32_t c0 = col[(size_t)b * 256], c1 = col[(size_t)(b + 1) * 256], c2 = col[(size_t)(b + 2) * 256],
-                   c3 = col[(size_t)(b + 3) * 256];
-    col[(size_t)b * 256] = off; off += c0;
-    col[(size_t)(b + 1) * 256] = off; off += c1;
-    col[(size_t)(b + 2) * 256] = off; off += c2;
-    col[(size_t)(b + 3) * 256] = off; off += c3;
-  }
-  for (; b < nblk; ++b) {
-    const uint32_t c = col[(size_t)b * 256];
-    col[(size_t)b * 256] = off;
-    off += c;
-  }
-}
-
+template <int RADIX_ITEMS>
 __global__ __launch_bounds__(U3D_BLOCK) void radix_scatter_kernel(int pass, int P, int nblk, const float* __restrict__ depth,
                                                                   const int32_t* __restrict__ radii,
                                                                   const uint32_t* __restrict__ keys_in,
@@ -138,12 +102,36 @@ __global__ __launch_bounds__(U3D_BLOCK) void radix_scatter_kernel(int pass, int 
   const int wave = tid >> 6;
   const uint32_t lane = u3d_lane_id();
   const size_t base = (size_t)view * P;
-  digit_base[tid] = hist[((size_t)view * nblk + blk) * 256 + tid];
+  {
+    // global offset of (digit tid, this block) in digit-major / block-minor order, from the per-block counts
+    // hist[view][b][digit] (every block redoes this small scan: no separate scan launch between histogram and scatter)
+    const uint32_t* col = hist + (size_t)view * nblk * 256 + tid;
+    uint32_t tot0 = 0, tot1 = 0, before = 0;
+    int b = 0;
+    for (; b + 1 < nblk; b += 2) {
+      const uint32_t c0 = col[(size_t)b * 256], c1 = col[(size_t)(b + 1) * 256];
+      tot0 += c0; tot1 += c1;
+      before += (b < blk ? c0 : 0u) + (b + 1 < blk ? c1 : 0u);
+    }
+    if (b < nblk) { const uint32_t c0 = col[(size_t)b * 256]; tot0 += c0; before += b < blk ? c0 : 0u; }
+    const uint32_t tot = tot0 + tot1;
+    digit_base[tid] = tot;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {   // inclusive Hillis-Steele scan of the 256 digit totals
+      const uint32_t v = tid >= o ? digit_base[tid - o] : 0u;
+      __syncthreads();
+      digit_base[tid] += v;
+      __syncthreads();
+    }
+    const uint32_t excl = digit_base[tid] - tot;
+    __syncthreads();
+    digit_base[tid] = excl + before;
+  }
 #pragma unroll
   for (int w = 0; w < 4; ++w) wave_cnt[w][tid] = 0;
   __syncthreads();
   for (int r = 0; r < RADIX_ITEMS; ++r) {
-    const int idx = blk * RADIX_TILE + r * U3D_BLOCK + tid;
+    const int idx = blk * (RADIX_ITEMS * U3D_BLOCK) + r * U3D_BLOCK + tid;
     const bool valid = idx < P;
     uint32_t k = 0, v = 0, digit = 0;
     if (valid) {
@@ -210,17 +198,22 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
                        b.depth, radii, b.rect, b.sorted_id, b.sorted_rect, b.n_vis);
     return;
   }
-  const int nblk = (d.P + RADIX_TILE - 1) / RADIX_TILE;
+  const int tile = u3d_radix_tile(d.P);
+  const int nblk = (d.P + tile - 1) / tile;
   for (int pass = 0; pass < 4; ++pass) {
     const uint32_t* kin = pass == 0 ? nullptr : b.sort_keys[(pass + 1) & 1];
     const uint32_t* vin = pass == 0 ? nullptr : b.sort_vals[(pass + 1) & 1];
     uint32_t* kout = b.sort_keys[pass & 1];
     uint32_t* vout = b.sort_vals[pass & 1];
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin,
-                       b.sort_hist);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(NV), dim3(U3D_BLOCK), 0, s, nblk, b.sort_hist);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin,
-                       vin, kout, vout, b.sort_hist);
+    if (tile == 1024) {
+      hipLaunchKernelGGL(radix_hist_kernel<4>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, b.sort_hist);
+      hipLaunchKernelGGL(radix_scatter_kernel<4>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, vin,
+                         kout, vout, b.sort_hist);
+    } else {
+      hipLaunchKernelGGL(radix_hist_kernel<16>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, b.sort_hist);
+      hipLaunchKernelGGL(radix_scatter_kernel<16>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, vin,
+                         kout, vout, b.sort_hist);
+    }
   }
   // pass 3 wrote buffer index 1
   hipLaunchKernelGGL(radix_finalize_kernel, dim3((d.P + U3D_BLOCK - 1) / U3D_BLOCK, NV), dim3(U3D_BLOCK), 0, s, d.P,
