@@ -409,8 +409,19 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_bwd_wave_kerne
 // The render loss needs nothing but the pixel's own colour and gt, so a tile can blend front to back, evaluate its
 // loss term and seed dL/dcolor, and immediately walk the same LDS-resident batch back to front: final_T, n_contrib and
 // the colour image never round-trip through HBM, the Gaussian batch is staged once, and one prologue disappears.
-// dL/dloss is taken as 1 (the result is linear in it; the host scales the stored gradient).  Same arithmetic, same
-// order as render_fwd_wave_kernel followed by render_bwd_wave_kernel<false>.
+// dL/dloss is taken as 1 (the result is linear in it; the host scales the stored gradient).
+//
+// Lane layout: lane>>2 is the tile ROW, the lane's 4 pixels are the consecutive COLUMNS 4*(lane&3)+k, so image rows
+// move as one 16-byte access per lane and channel, and a DPP quad (4 lanes) is one 16-pixel tile row: everything a
+// quad sums shares dy.  The kernel is VALU-issue bound, so the arithmetic is arranged for instruction count:
+//   * exponent  pw = (a' dx + b' dy) dx + c' dy^2  with the -log2e/2 factors folded in at staging (3 ops/pixel);
+//   * the "colour behind" recurrence runs on the scalar  A = sum_c behind_c * dL/dC_c  (dL/dC is constant per pixel),
+//     not per channel; the update tolerates alpha = 0, so non-contributing pixels take the same straight-line code
+//     with their alpha selected to zero (no per-pixel branches, no copies);
+//   * only m0, mx, mxx and the colour gradient are accumulated per pixel; after the two quad levels of the
+//     reduction  my = dy m0, mxy = dy mx, myy = dy my;
+//   * the half-row and row levels use DPP bank masks to deposit two values into one register per instruction pair
+//     (9 values -> 5 -> 3 registers), and the four rows of the wave meet in three LDS float adds.
 __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel(
     int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t nblocks, size_t NG,
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis,
@@ -418,10 +429,10 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
     const float* __restrict__ bg, float* __restrict__ out_color, double* __restrict__ acc, float* __restrict__ part,
     U3DLoss loss) {
   constexpr int NK = U3D_NACC - 1;
-  __shared__ float4 sA[BWD_WAVES][U3D_WAVE];   // x, y, a, b
-  __shared__ float4 sB[BWD_WAVES][U3D_WAVE];   // c, opacity, 1/depth, pos (bits)
+  __shared__ float4 sA[BWD_WAVES][U3D_WAVE];   // x, y, a' = -log2e/2 a, b' = -log2e b
+  __shared__ float4 sB[BWD_WAVES][U3D_WAVE];   // c' = -log2e/2 c, opacity, -, pos (bits)
   __shared__ float4 sC[BWD_WAVES][U3D_WAVE];   // r, g, b, id (bits)
-  __shared__ float4 sAcc[BWD_WAVES][U3D_WAVE][3];   // per slot: {mx,my,mxx,mxy} {myy,m0,r,g} {b,d,-,-}
+  __shared__ float4 sAcc[BWD_WAVES][U3D_WAVE][3];   // per slot: {mx,my,mxx,mxy} {myy,m0,r,g} {b,-,-,-}
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t lid = u3d_xcd_remap(blockIdx.x, nblocks) * (uint32_t)BWD_WAVES + (uint32_t)wave;
@@ -429,9 +440,9 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
   const int view = (int)(lid / T);
   const int tile = (int)lid - view * T;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  const int px = tx * U3D_TILE + (lane & 15);
-  const int py0 = ty * U3D_TILE + (lane >> 4);
-  const float pxf = (float)px;
+  const int py = ty * U3D_TILE + (lane >> 2);
+  const int px0 = tx * U3D_TILE + 4 * (lane & 3);
+  const float pyf = (float)py;
   const size_t vbase = (size_t)view * P;
   const size_t npix = (size_t)H * W;
   const uint32_t nv = n_vis[view];
@@ -451,8 +462,8 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
       const float2 m = xy[g];
       const float4 co = conic_op[g];
       const float4 cd = rgbd[g];
-      sA[wave][o] = make_float4(m.x, m.y, co.x, co.y);
-      sB[wave][o] = make_float4(co.z, co.w, 1.0f / cd.w, __uint_as_float(s + 1u));
+      sA[wave][o] = make_float4(m.x, m.y, (-0.5f * LOG2E) * co.x, -LOG2E * co.y);
+      sB[wave][o] = make_float4((-0.5f * LOG2E) * co.z, co.w, 0.f, __uint_as_float(s + 1u));
       sC[wave][o] = make_float4(cd.x, cd.y, cd.z, __uint_as_float(id));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -460,24 +471,25 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
     return bal;
   };
 
-  float pyf[4], Tr[4], C0[4], C1[4], C2[4];
-  uint32_t last[4];
-  bool done[4];
+  float pxf[4], Tr[4], C0[4], C1[4], C2[4], amin[4];
+  uint32_t stop_pos[4];   // sorted position at which the pixel saturated (entries from there on are not blended)
+  bool inside[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int py = py0 + 4 * k;
-    pyf[k] = (float)py;
-    Tr[k] = 1.f; C0[k] = C1[k] = C2[k] = 0.f; last[k] = 0u;
-    done[k] = !(px < W && py < H);
+    pxf[k] = (float)(px0 + k);
+    inside[k] = px0 + k < W && py < H;
+    Tr[k] = 1.f; C0[k] = C1[k] = C2[k] = 0.f;
+    amin[k] = inside[k] ? ALPHA_MIN : 2.f;          // a finished pixel accepts no alpha (alpha <= 0.99)
+    stop_pos[k] = inside[k] ? 0xffffffffu : 0u;
   }
-  bool all_done = done[0] && done[1] && done[2] && done[3];
 
   // ---------------- forward ----------------
+  uint32_t wlast = 0;   // wave-uniform: last sorted position that contributed to any pixel of the tile
+  bool wave_done = false;
   int staged = -1;
   unsigned long long staged_bal = 0ull;
   const int nbf = (int)((nv + U3D_WAVE - 1) / U3D_WAVE);
-  for (int b = 0; b < nbf; ++b) {
-    if (__ballot(!all_done) == 0ull) break;
+  for (int b = 0; b < nbf && !wave_done; ++b) {
     const unsigned long long bal = stage(b, nv);
     staged = b; staged_bal = bal;
     const int total = __popcll(bal);
@@ -485,86 +497,110 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
       const float4 A = sA[wave][j];
       const float4 B = sB[wave][j];
       const float4 Cc = sC[wave][j];
-      const float dx = A.x - pxf;
-      const float adx = (-0.5f * LOG2E * A.z) * dx, bdx = (-LOG2E * A.w) * dx, cl = -0.5f * LOG2E * B.x;
+      const float dy = A.y - pyf;
+      const float bdy = A.w * dy, cdy2 = (B.x * dy) * dy;
+      bool contrib = false, stopped = false;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float dy = A.y - pyf[k];
-        const float pw = fmaf(adx, dx, fmaf(cl * dy, dy, bdx * dy));
+        const float dx = A.x - pxf[k];
+        const float pw = fmaf(fmaf(A.z, dx, bdy), dx, cdy2);
         const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(pw));
-        const bool ok = !done[k] && pw <= 0.f && alpha >= ALPHA_MIN;
+        const bool ok = pw <= 0.f && alpha >= amin[k];
         const float test_T = Tr[k] * (1.f - alpha);
         const bool stop = ok && test_T < T_STOP;
-        done[k] = done[k] || stop;
         if (ok && !stop) {
           const float w = alpha * Tr[k];
           C0[k] = fmaf(Cc.x, w, C0[k]);
           C1[k] = fmaf(Cc.y, w, C1[k]);
           C2[k] = fmaf(Cc.z, w, C2[k]);
           Tr[k] = test_T;
-          last[k] = __float_as_uint(B.w);
+          contrib = true;
+        }
+        if (stop) {
+          amin[k] = 2.f;
+          stop_pos[k] = __float_as_uint(B.w);
+          stopped = true;
         }
       }
-      all_done = done[0] && done[1] && done[2] && done[3];
-      if (__ballot(!all_done) == 0ull) break;
+      if (__ballot(contrib) != 0ull) wlast = __builtin_amdgcn_readfirstlane(__float_as_uint(B.w));
+      if (__ballot(stopped) != 0ull) {
+        const bool all_done = amin[0] > 1.f && amin[1] > 1.f && amin[2] > 1.f && amin[3] > 1.f;
+        if (__ballot(!all_done) == 0ull) { wave_done = true; break; }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
 
   // ---------------- loss term, dL/dcolor seed ----------------
-  float T_final[4], dp0[4], dp1[4], dp2[4], bg_dot[4];
+  float dp0[4], dp1[4], dp2[4], tfb[4];
   float e = 0.f;
-  uint32_t wmax = 0;
-  const float sc = loss.inv_count;   // dL/dloss == 1
+  {
+    const float sc = loss.inv_count;   // dL/dloss == 1
+    const size_t pid0 = (size_t)py * W + px0;
+    const float* gp = loss.gt + (size_t)view * 3 * npix + pid0;
+    float* oc = out_color ? out_color + (size_t)view * 3 * npix + pid0 : nullptr;
+    float o0[4], o1[4], o2[4], g0[4], g1[4], g2[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int py = py0 + 4 * k;
-    T_final[k] = 0.f; dp0[k] = dp1[k] = dp2[k] = 0.f;
-    if (px < W && py < H) {
-      const size_t pid = (size_t)py * W + px;
-      T_final[k] = Tr[k];
-      const float o0 = fmaf(Tr[k], bg[0], C0[k]), o1 = fmaf(Tr[k], bg[1], C1[k]), o2 = fmaf(Tr[k], bg[2], C2[k]);
-      if (out_color) {
-        float* oc = out_color + (size_t)view * 3 * npix + pid;
-        oc[0] = o0; oc[npix] = o1; oc[2 * npix] = o2;
-      }
-      const float* gp = loss.gt + (size_t)view * 3 * npix + pid;
-      const float g0 = gp[0], g1 = gp[npix], g2 = gp[2 * npix];
-      const float d0 = o0 - g0, d1 = o1 - g1, d2 = o2 - g2;
-      e += loss_pixel(loss, bg, g0, g1, g2, d0, d1, d2);
-      if (loss.kind == 3) {
-        dp0[k] = sc * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
-        dp1[k] = sc * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
-        dp2[k] = sc * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
-      } else {
-        const float w2 = 2.f * sc * focal_weight(loss, bg, g0, g1, g2);
-        dp0[k] = w2 * d0; dp1[k] = w2 * d1; dp2[k] = w2 * d2;
+    for (int k = 0; k < 4; ++k) {
+      o0[k] = fmaf(Tr[k], bg[0], C0[k]); o1[k] = fmaf(Tr[k], bg[1], C1[k]); o2[k] = fmaf(Tr[k], bg[2], C2[k]);
+      g0[k] = g1[k] = g2[k] = 0.f;
+    }
+    if ((W & 3) == 0) {
+      if (inside[0]) {   // the lane's four pixels are in or out together
+        const float4 a = *reinterpret_cast<const float4*>(gp);
+        const float4 b4 = *reinterpret_cast<const float4*>(gp + npix);
+        const float4 c = *reinterpret_cast<const float4*>(gp + 2 * npix);
+        g0[0] = a.x; g0[1] = a.y; g0[2] = a.z; g0[3] = a.w;
+        g1[0] = b4.x; g1[1] = b4.y; g1[2] = b4.z; g1[3] = b4.w;
+        g2[0] = c.x; g2[1] = c.y; g2[2] = c.z; g2[3] = c.w;
+        if (oc) {
+          *reinterpret_cast<float4*>(oc) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+          *reinterpret_cast<float4*>(oc + npix) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+          *reinterpret_cast<float4*>(oc + 2 * npix) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+        }
       }
     } else {
-      last[k] = 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (inside[k]) {
+          g0[k] = gp[k]; g1[k] = gp[npix + k]; g2[k] = gp[2 * npix + k];
+          if (oc) { oc[k] = o0[k]; oc[npix + k] = o1[k]; oc[2 * npix + k] = o2[k]; }
+        }
     }
-    bg_dot[k] = bg[0] * dp0[k] + bg[1] * dp1[k] + bg[2] * dp2[k];
-    wmax = max(wmax, last[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      dp0[k] = dp1[k] = dp2[k] = 0.f;
+      if (inside[k]) {
+        const float d0 = o0[k] - g0[k], d1 = o1[k] - g1[k], d2 = o2[k] - g2[k];
+        e += loss_pixel(loss, bg, g0[k], g1[k], g2[k], d0, d1, d2);
+        if (loss.kind == 3) {
+          dp0[k] = sc * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
+          dp1[k] = sc * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+          dp2[k] = sc * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
+        } else {
+          const float w2 = 2.f * sc * focal_weight(loss, bg, g0[k], g1[k], g2[k]);
+          dp0[k] = w2 * d0; dp1[k] = w2 * d1; dp2[k] = w2 * d2;
+        }
+      } else {
+        Tr[k] = 0.f;
+      }
+      tfb[k] = Tr[k] * (bg[0] * dp0[k] + bg[1] * dp1[k] + bg[2] * dp2[k]);   // T_final * (bg . dL/dC)
+    }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    e += __shfl_xor(e, o);
-    wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o));
-  }
+  for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
   if (lane == 0) loss.partial[lid] = e;
 
   // ---------------- backward ----------------
-  // "colour behind" recurrence  ar <- la*lc + (1-la)*ar  kept as  ar <- fma(oml, ar, u)  with u = la*lc, oml = 1-la
-  float ar0[4], ar1[4], ar2[4], u0[4], u1[4], u2[4], oml[4], tfb[4];
+  // "behind" recurrence  A <- la*(lc . dp) + (1-la)*A  kept as  A <- fma(oml, A, U)  with U = la*(lc . dp), oml = 1-la
+  float Ak[4], Uk[4], oml[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    Tr[k] = T_final[k];
-    ar0[k] = ar1[k] = ar2[k] = u0[k] = u1[k] = u2[k] = 0.f;
-    oml[k] = 1.f;
-    tfb[k] = T_final[k] * bg_dot[k];
-  }
+  for (int k = 0; k < 4; ++k) { Ak[k] = 0.f; Uk[k] = 0.f; oml[k] = 1.f; }
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+  const uint32_t wmax = wlast;
+  const bool row_lane = (lane & 3) == 0, first_lane = (lane & 15) == 0;
+  const int bank = (lane >> 2) & 3;
   const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
   for (int b = nb - 1; b >= 0; --b) {
     unsigned long long bal = staged_bal;
@@ -577,58 +613,87 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
       const float4 B = sB[wave][j];
       const float4 Cc = sC[wave][j];
       const uint32_t pos = __float_as_uint(B.w);
-      const float dx = A.x - pxf;
-      const float adx = (-0.5f * LOG2E * A.z) * dx, bdx = (-LOG2E * A.w) * dx, cl = -0.5f * LOG2E * B.x;
-      float m0 = 0.f, mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+      const float dy = A.y - pyf;
+      const float bdy = A.w * dy, cdy2 = (B.x * dy) * dy;
+      float dx[4], ae[4];
       bool any = false;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float dy = A.y - pyf[k];
-        const float pw = fmaf(adx, dx, fmaf(cl * dy, dy, bdx * dy));
-        const float G = __builtin_amdgcn_exp2f(pw);
-        const float alpha = fminf(0.99f, B.y * G);
-        const bool ok = pos <= last[k] && pw <= 0.f && alpha >= ALPHA_MIN;
-        if (ok) {
-          any = true;
-          const float om = 1.f - alpha;
-          const float rc = __builtin_amdgcn_rcpf(om);
-          Tr[k] = Tr[k] * rc;
-          const float w = alpha * Tr[k];
-          ar0[k] = fmaf(oml[k], ar0[k], u0[k]); u0[k] = alpha * Cc.x;
-          ar1[k] = fmaf(oml[k], ar1[k], u1[k]); u1[k] = alpha * Cc.y;
-          ar2[k] = fmaf(oml[k], ar2[k], u2[k]); u2[k] = alpha * Cc.z;
-          oml[k] = om;
-          float dL_dalpha = (Cc.x - ar0[k]) * dp0[k] + (Cc.y - ar1[k]) * dp1[k] + (Cc.z - ar2[k]) * dp2[k];
-          g_r = fmaf(w, dp0[k], g_r); g_g = fmaf(w, dp1[k], g_g); g_b = fmaf(w, dp2[k], g_b);
-          dL_dalpha = fmaf(dL_dalpha, Tr[k], -(tfb[k] * rc));
-          const float q = B.y * dL_dalpha * G;
-          const float qdx = q * dx, qdy = q * dy;
-          m0 += q; mx += qdx; my += qdy;
-          mxx = fmaf(qdx, dx, mxx); mxy = fmaf(qdx, dy, mxy); myy = fmaf(qdy, dy, myy);
-        }
+        dx[k] = A.x - pxf[k];
+        const float pw = fmaf(fmaf(A.z, dx[k], bdy), dx[k], cdy2);
+        const float araw = B.y * __builtin_amdgcn_exp2f(pw);   // opacity * G (alpha before the 0.99 clamp)
+        const bool ok = pos < stop_pos[k] && pw <= 0.f && araw >= ALPHA_MIN;
+        any = any || ok;
+        ae[k] = ok ? araw : 0.f;
       }
       if (__ballot(any) == 0ull) continue;
-#define U3D_DPP9(CTRL)                                                                                              \
-  asm volatile("s_nop 1\n\t"                                                                                        \
-               "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\t"                        \
-               "v_add_f32_dpp %2, %2, %2 " CTRL "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\t"                        \
-               "v_add_f32_dpp %4, %4, %4 " CTRL "\n\tv_add_f32_dpp %5, %5, %5 " CTRL "\n\t"                        \
-               "v_add_f32_dpp %6, %6, %6 " CTRL "\n\tv_add_f32_dpp %7, %7, %7 " CTRL "\n\t"                        \
-               "v_add_f32_dpp %8, %8, %8 " CTRL "\n\ts_nop 1"                                                       \
-               : "+v"(m0), "+v"(mx), "+v"(my), "+v"(mxx), "+v"(mxy), "+v"(myy), "+v"(g_r), "+v"(g_g), "+v"(g_b))
-      U3D_DPP9("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
-      U3D_DPP9("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-      U3D_DPP9("row_half_mirror row_mask:0xf bank_mask:0xf");
-      U3D_DPP9("row_mirror row_mask:0xf bank_mask:0xf");
-      U3D_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf");
-      U3D_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf");
-#undef U3D_DPP9
-      if (lane == 63) {
-        const int slot = b == 0 ? (int)pos - 1 : j;
-        sAcc[wave][slot][0] = make_float4(mx, my, mxx, mxy);
-        sAcc[wave][slot][1] = make_float4(myy, m0, g_r, g_g);
-        sAcc[wave][slot][2] = make_float4(g_b, 0.f, 0.f, 0.f);
+      float m0 = 0.f, mx = 0.f, mxx = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float alpha = fminf(0.99f, ae[k]);
+        const float om = 1.f - alpha;
+        const float rc = __builtin_amdgcn_rcpf(om);
+        Tr[k] = Tr[k] * rc;
+        const float w = alpha * Tr[k];
+        const float cdp = fmaf(Cc.z, dp2[k], fmaf(Cc.y, dp1[k], Cc.x * dp0[k]));
+        Ak[k] = fmaf(oml[k], Ak[k], Uk[k]);
+        Uk[k] = alpha * cdp;
+        oml[k] = om;
+        const float dL_dalpha = fmaf(cdp - Ak[k], Tr[k], -(tfb[k] * rc));
+        g_r = fmaf(w, dp0[k], g_r); g_g = fmaf(w, dp1[k], g_g); g_b = fmaf(w, dp2[k], g_b);
+        const float q = ae[k] * dL_dalpha;    // dL/dG * G
+        const float qdx = q * dx[k];
+        m0 += q; mx += qdx;
+        mxx = fmaf(qdx, dx[k], mxx);
       }
+      // quad levels (one tile row of 16 pixels per quad); v_add_f32_dpp by hand: hipcc does not fuse update_dpp + fadd
+      // (-0.0 rule).  Dependent DPP ops stay >= 2 instructions apart (VALU write -> DPP read hazard).
+      asm volatile("s_nop 1\n\t"
+                   "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                   "s_nop 1"
+                   : "+v"(m0), "+v"(mx), "+v"(mxx), "+v"(g_r), "+v"(g_g), "+v"(g_b));
+      float my = dy * m0, mxy = dy * mx;
+      float myy = dy * my;
+      // half-row level (lanes i <-> 7-i: banks 0<->1, 2<->3), two values per register: banks {0,2} keep the first
+      // operand's sums, banks {1,3} receive the second's; then the row level (i <-> i+8: banks 0<->2, 1<->3) the same way:
+      //   mx  <- {mx, my, mxx, mxy}    myy <- {myy, m0, g_r, g_g}    g_b <- g_b     (bank index = component)
+      asm volatile("s_nop 1\n\t"
+                   "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                   "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                   "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                   "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                   "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %0, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                   "v_add_f32_dpp %1, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                   "v_add_f32_dpp %2, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                   "v_add_f32_dpp %3, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                   "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                   "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                   "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                   "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                   "s_nop 1"
+                   : "+v"(mx), "+v"(mxx), "+v"(myy), "+v"(g_r), "+v"(g_b)
+                   : "v"(my), "v"(mxy), "v"(m0), "v"(g_g));
+      // the four 16-lane rows meet in LDS: batch 0 is indexed by sorted position (merged across tiles by
+      // bwd_reduce_kernel), later batches by compaction slot
+      float* sl = reinterpret_cast<float*>(&sAcc[wave][b == 0 ? (int)pos - 1 : j][0]);
+      if (row_lane) {
+        atomicAdd(sl + bank, mx);
+        atomicAdd(sl + 4 + bank, myy);
+      }
+      if (first_lane) atomicAdd(sl + 8, g_b);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -636,11 +701,11 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
       if (lane < total) {
         const size_t g = vbase + __float_as_uint(sC[wave][lane].w);
         const float4 m0v = sAcc[wave][lane][0], m1v = sAcc[wave][lane][1], m2v = sAcc[wave][lane][2];
-        const float4 Ag = sA[wave][lane], Bg = sB[wave][lane];
+        const float4 co = conic_op[g];
         const float m[U3D_NACC] = {m0v.x, m0v.y, m0v.z, m0v.w, m1v.x, m1v.y, m1v.z, m1v.w, m2v.x, m2v.y};
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-          const float v = moment_to_acc<float>(k, m, Ag.z, Ag.w, Bg.x, Bg.y, ddelx_dx, ddely_dy);
+          const float v = moment_to_acc<float>(k, m, co.x, co.y, co.z, co.w, ddelx_dx, ddely_dy);
           if (v != 0.f) unsafeAtomicAdd(&acc[(size_t)k * NG + g], (double)v);
         }
       }
