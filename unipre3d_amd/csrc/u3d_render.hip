@@ -38,6 +38,31 @@ __device__ __forceinline__ float loss_pixel(const U3DLoss& L, const float* __res
   return focal_weight(L, bg, g0, g1, g2) * (d0 * d0 + d1 * d1 + d2 * d2);
 }
 
+
+// ---- lane-mask helpers -------------------------------------------------------------------------------
+// Compare results are kept as 64-bit lane masks on the scalar unit (v_cmp -> SGPR pair, s_and/s_or), and applied with
+// one v_cndmask; hipcc's own lowering of bool && / ballot costs two extra VALU instructions per use.
+#define U3D_FCMP_OGE 3
+#define U3D_FCMP_OLT 4
+#define U3D_FCMP_OLE 5
+#define U3D_ICMP_ULT 36
+typedef unsigned long long lanemask_t;
+__device__ __forceinline__ float mask_sel0(lanemask_t m, float a) {   // lane in m ? a : 0
+  float r;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(m));
+  return r;
+}
+__device__ __forceinline__ float mask_sel(lanemask_t m, float a, float b) {   // lane in m ? a : b
+  float r;
+  asm("v_cndmask_b32_e64 %0, %2, %1, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+  return r;
+}
+__device__ __forceinline__ float min_099(float a) {   // fminf(0.99f, a) without the canonicalising v_max
+  float r;
+  asm("v_min_f32_e32 %0, 0x3f7d70a4, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+
 // ---- forward, wave-per-tile form ---------------------------------------------------------------
 // One WAVE renders one 16x16 tile, 4 pixels per lane (column lane&15, rows (lane>>4)+4k): the per-Gaussian LDS
 // broadcast reads, loop control and exponent set-up are shared by 4 pixels (4-way ILP), batches are 64 sorted
@@ -485,6 +510,7 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
 
   // ---------------- forward ----------------
   uint32_t wlast = 0;   // wave-uniform: last sorted position that contributed to any pixel of the tile
+  int jlast = 0, blast = -1;
   bool wave_done = false;
   int staged = -1;
   unsigned long long staged_bal = 0ull;
@@ -499,35 +525,36 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
       const float4 Cc = sC[wave][j];
       const float dy = A.y - pyf;
       const float bdy = A.w * dy, cdy2 = (B.x * dy) * dy;
-      bool contrib = false, stopped = false;
+      lanemask_t contrib = 0ull, stopped = 0ull;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float dx = A.x - pxf[k];
         const float pw = fmaf(fmaf(A.z, dx, bdy), dx, cdy2);
-        const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(pw));
-        const bool ok = pw <= 0.f && alpha >= amin[k];
-        const float test_T = Tr[k] * (1.f - alpha);
-        const bool stop = ok && test_T < T_STOP;
-        if (ok && !stop) {
-          const float w = alpha * Tr[k];
-          C0[k] = fmaf(Cc.x, w, C0[k]);
-          C1[k] = fmaf(Cc.y, w, C1[k]);
-          C2[k] = fmaf(Cc.z, w, C2[k]);
-          Tr[k] = test_T;
-          contrib = true;
-        }
-        if (stop) {
-          amin[k] = 2.f;
-          stop_pos[k] = __float_as_uint(B.w);
-          stopped = true;
+        const float alpha = min_099(B.y * __builtin_amdgcn_exp2f(pw));
+        const lanemask_t m_ok = __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE) & __builtin_amdgcn_fcmpf(alpha, amin[k], U3D_FCMP_OGE);
+        const float w = alpha * Tr[k];
+        const float test_T = Tr[k] - w;          // T (1 - alpha)
+        const lanemask_t m_lt = __builtin_amdgcn_fcmpf(test_T, T_STOP, U3D_FCMP_OLT);
+        const lanemask_t m_c = m_ok & ~m_lt, m_s = m_ok & m_lt;
+        const float we = mask_sel0(m_c, w);      // blended weight, 0 for pixels that skip this Gaussian
+        C0[k] = fmaf(Cc.x, we, C0[k]);
+        C1[k] = fmaf(Cc.y, we, C1[k]);
+        C2[k] = fmaf(Cc.z, we, C2[k]);
+        Tr[k] -= we;
+        contrib |= m_c;
+        stopped |= m_s;
+        if (m_s != 0ull) {   // rare, wave-uniform
+          amin[k] = mask_sel(m_s, 2.f, amin[k]);
+          stop_pos[k] = __float_as_uint(mask_sel(m_s, B.w, __uint_as_float(stop_pos[k])));
         }
       }
-      if (__ballot(contrib) != 0ull) wlast = __builtin_amdgcn_readfirstlane(__float_as_uint(B.w));
-      if (__ballot(stopped) != 0ull) {
+      if (contrib != 0ull) { jlast = j; blast = b; }
+      if (stopped != 0ull) {
         const bool all_done = amin[0] > 1.f && amin[1] > 1.f && amin[2] > 1.f && amin[3] > 1.f;
         if (__ballot(!all_done) == 0ull) { wave_done = true; break; }
       }
     }
+    if (blast == b) wlast = __builtin_amdgcn_readfirstlane(__float_as_uint(sB[wave][jlast].w));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -616,35 +643,41 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
       const float dy = A.y - pyf;
       const float bdy = A.w * dy, cdy2 = (B.x * dy) * dy;
       float dx[4], ae[4];
-      bool any = false;
+      lanemask_t any = 0ull;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         dx[k] = A.x - pxf[k];
         const float pw = fmaf(fmaf(A.z, dx[k], bdy), dx[k], cdy2);
         const float araw = B.y * __builtin_amdgcn_exp2f(pw);   // opacity * G (alpha before the 0.99 clamp)
-        const bool ok = pos < stop_pos[k] && pw <= 0.f && araw >= ALPHA_MIN;
-        any = any || ok;
-        ae[k] = ok ? araw : 0.f;
+        const lanemask_t m = __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE) & __builtin_amdgcn_fcmpf(araw, ALPHA_MIN, U3D_FCMP_OGE) &
+                             __builtin_amdgcn_uicmp(pos, stop_pos[k], U3D_ICMP_ULT);
+        any |= m;
+        ae[k] = mask_sel0(m, araw);
       }
-      if (__ballot(any) == 0ull) continue;
-      float m0 = 0.f, mx = 0.f, mxx = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+      if (any == 0ull) continue;
+      float m0, mx, mxx, g_r, g_g, g_b;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float alpha = fminf(0.99f, ae[k]);
+        const float alpha = min_099(ae[k]);
         const float om = 1.f - alpha;
         const float rc = __builtin_amdgcn_rcpf(om);
         Tr[k] = Tr[k] * rc;
         const float w = alpha * Tr[k];
         const float cdp = fmaf(Cc.z, dp2[k], fmaf(Cc.y, dp1[k], Cc.x * dp0[k]));
-        Ak[k] = fmaf(oml[k], Ak[k], Uk[k]);
+        asm("v_fma_f32 %0, %1, %0, %2" : "+v"(Ak[k]) : "v"(oml[k]), "v"(Uk[k]));   // in place (no register rotation)
         Uk[k] = alpha * cdp;
         oml[k] = om;
         const float dL_dalpha = fmaf(cdp - Ak[k], Tr[k], -(tfb[k] * rc));
-        g_r = fmaf(w, dp0[k], g_r); g_g = fmaf(w, dp1[k], g_g); g_b = fmaf(w, dp2[k], g_b);
         const float q = ae[k] * dL_dalpha;    // dL/dG * G
         const float qdx = q * dx[k];
-        m0 += q; mx += qdx;
-        mxx = fmaf(qdx, dx[k], mxx);
+        if (k == 0) {
+          g_r = w * dp0[k]; g_g = w * dp1[k]; g_b = w * dp2[k];
+          m0 = q; mx = qdx; mxx = qdx * dx[k];
+        } else {
+          g_r = fmaf(w, dp0[k], g_r); g_g = fmaf(w, dp1[k], g_g); g_b = fmaf(w, dp2[k], g_b);
+          m0 += q; mx += qdx;
+          mxx = fmaf(qdx, dx[k], mxx);
+        }
       }
       // quad levels (one tile row of 16 pixels per quad); v_add_f32_dpp by hand: hipcc does not fuse update_dpp + fadd
       // (-0.0 rule).  Dependent DPP ops stay >= 2 instructions apart (VALU write -> DPP read hazard).
