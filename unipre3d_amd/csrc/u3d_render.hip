@@ -620,10 +620,10 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
   if (lane == 0) loss.partial[lid] = e;
 
   // ---------------- backward ----------------
-  // "behind" recurrence  A <- la*(lc . dp) + (1-la)*A  kept as  A <- fma(oml, A, U)  with U = la*(lc . dp), oml = 1-la
-  float Ak[4], Uk[4], oml[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { Ak[k] = 0.f; Uk[k] = 0.f; oml[k] = 1.f; }
+  // With  R_i = sum_{j behind i} w_j (c_j . dL/dC) + T_final (bg . dL/dC)  (everything behind Gaussian i, weighted by dL/dC)
+  //   dL/dalpha_i = T_i (c_i . dL/dC) - R_i / (1 - alpha_i),      R_{i-1} = R_i + w_i (c_i . dL/dC),
+  // the same quantity as the reference's normalised "accum_rec" form ((c_i - accum_rec) T_i - T_final/(1-alpha_i) bg.dL/dC)
+  // in three instructions and one running value per pixel; tfb[] seeds R.
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
   const uint32_t wmax = wlast;
   const bool row_lane = (lane & 3) == 0, first_lane = (lane & 15) == 0;
@@ -661,13 +661,12 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
         const float alpha = min_099(ae[k]);
         const float om = 1.f - alpha;
         const float rc = __builtin_amdgcn_rcpf(om);
-        Tr[k] = Tr[k] * rc;
-        const float w = alpha * Tr[k];
+        const float Tn = Tr[k] * rc;            // T in front of this Gaussian
+        const float w = alpha * Tn;
+        Tr[k] = Tn;
         const float cdp = fmaf(Cc.z, dp2[k], fmaf(Cc.y, dp1[k], Cc.x * dp0[k]));
-        asm("v_fma_f32 %0, %1, %0, %2" : "+v"(Ak[k]) : "v"(oml[k]), "v"(Uk[k]));   // in place (no register rotation)
-        Uk[k] = alpha * cdp;
-        oml[k] = om;
-        const float dL_dalpha = fmaf(cdp - Ak[k], Tr[k], -(tfb[k] * rc));
+        const float dL_dalpha = fmaf(Tn, cdp, -(tfb[k] * rc));
+        tfb[k] = fmaf(w, cdp, tfb[k]);
         const float q = ae[k] * dL_dalpha;    // dL/dG * G
         const float qdx = q * dx[k];
         if (k == 0) {
