@@ -525,9 +525,9 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
       const float4 Cc = sC[wave][j];
       const float dy = A.y - pyf;
       const float bdy = A.w * dy, cdy2 = (B.x * dy) * dy;
-      lanemask_t contrib = 0ull, stopped = 0ull;
+      lanemask_t contrib = 0ull, stopped = 0ull, m_stop[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < 4; ++k) {   // one basic block: the four pixels' dependency chains interleave
         const float dx = A.x - pxf[k];
         const float pw = fmaf(fmaf(A.z, dx, bdy), dx, cdy2);
         const float alpha = min_099(B.y * __builtin_amdgcn_exp2f(pw));
@@ -535,17 +535,21 @@ __global__ __launch_bounds__(BWD_WAVES * U3D_WAVE, 4) void render_fb_wave_kernel
         const float w = alpha * Tr[k];
         const float test_T = Tr[k] - w;          // T (1 - alpha)
         const lanemask_t m_lt = __builtin_amdgcn_fcmpf(test_T, T_STOP, U3D_FCMP_OLT);
-        const lanemask_t m_c = m_ok & ~m_lt, m_s = m_ok & m_lt;
+        const lanemask_t m_c = m_ok & ~m_lt;
+        m_stop[k] = m_ok & m_lt;
         const float we = mask_sel0(m_c, w);      // blended weight, 0 for pixels that skip this Gaussian
         C0[k] = fmaf(Cc.x, we, C0[k]);
         C1[k] = fmaf(Cc.y, we, C1[k]);
         C2[k] = fmaf(Cc.z, we, C2[k]);
         Tr[k] -= we;
         contrib |= m_c;
-        stopped |= m_s;
-        if (m_s != 0ull) {   // rare, wave-uniform
-          amin[k] = mask_sel(m_s, 2.f, amin[k]);
-          stop_pos[k] = __float_as_uint(mask_sel(m_s, B.w, __uint_as_float(stop_pos[k])));
+        stopped |= m_stop[k];
+      }
+      if (stopped != 0ull) {   // rare, wave-uniform: pixels saturating at this Gaussian
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          amin[k] = mask_sel(m_stop[k], 2.f, amin[k]);
+          stop_pos[k] = __float_as_uint(mask_sel(m_stop[k], B.w, __uint_as_float(stop_pos[k])));
         }
       }
       if (contrib != 0ull) { jlast = j; blast = b; }
