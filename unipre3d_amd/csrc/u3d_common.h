@@ -33,7 +33,8 @@ struct U3DBuffers {
   uint32_t* sort_hist;     // radix histograms
   // image
   float* final_T;        // [NV*H*W]
-  uint32_t* n_contrib;   // [NV*H*W]  sorted position + 1 of the last contributor
+  uint32_t* n_contrib;   // [NV*H*W]  exclusive sorted-position limit of the pixel (position at which it saturated, else UINT_MAX)
+  uint32_t* tile_last;   // [NV*T]    last sorted position that contributed to any pixel of the tile
 };
 
 // Where the per-Gaussian parameters of set `item`, Gaussian `i` come from.
@@ -139,6 +140,7 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
   char* im = (char*)image;
   CARVE(im, final_T, float, NP);
   CARVE(im, n_contrib, uint32_t, NP);
+  CARVE(im, tile_last, uint32_t, NV * (size_t)((d.image_width + U3D_TILE - 1) / U3D_TILE) * ((d.image_height + U3D_TILE - 1) / U3D_TILE));
   L.image_bytes = o > 0 ? o : 256;
 #undef CARVE
   // f64 accumulators: global_atomic_add_f64 makes the cross-tile sum order-insensitive at fp32 output precision
