@@ -70,6 +70,7 @@ U3DSource head_source(const u3d_raster_desc& d, const u3d_head_desc& h, const fl
   src.center = center;
   src.offset_scale = h.offset_scale;
   src.qnorm = qnorm;
+  src.qnorm_out = nullptr; src.qdot_zero = nullptr;
   (void)d;
   return src;
 }
@@ -249,11 +250,14 @@ int u3d_render_loss_forward(const u3d_raster_desc* desc, const u3d_head_desc* he
   U3DFused f{};
   u3d_carve_fused(d, fused, &f);
   if (d.flags & U3D_FLAG_STATS) (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
-  if (head->mode == 1) u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, nullptr, s);
+  U3DSource src = head_source(d, *head, head_out, center, f.qnorm);
+  if (head->mode == 1) {
+    if (u3d_preprocess_sorts(d)) src.qnorm_out = f.qnorm;   // P <= 256: norms computed inside preprocess_fwd
+    else u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, nullptr, s);
+  }
   {
     ProfScope ps(0, s);
-    u3d_launch_preprocess_fwd(d, b, head_source(d, *head, head_out, center, f.qnorm), viewmatrix, projmatrix, campos, radii,
-                              nullptr, s);
+    u3d_launch_preprocess_fwd(d, b, src, viewmatrix, projmatrix, campos, radii, nullptr, s);
   }
   if (!u3d_preprocess_sorts(d)) {
     ProfScope ps(1, s);
@@ -330,8 +334,11 @@ int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head,
   float* part = (float*)((char*)backward_scratch + Lay.acc_bytes);
   if (d.flags & U3D_FLAG_STATS) (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
   // no memset nodes: quat_norms clears qdot, preprocess_fwd clears the accumulators of the (view, Gaussian) it projects
-  if (head->mode == 1) u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, f.qdot, s);
-  const U3DSource src = head_source(d, *head, head_out, center, f.qnorm);
+  U3DSource src = head_source(d, *head, head_out, center, f.qnorm);
+  if (head->mode == 1) {
+    if (u3d_preprocess_sorts(d)) { src.qnorm_out = f.qnorm; src.qdot_zero = f.qdot; }   // P <= 256: inside preprocess_fwd
+    else u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, f.qdot, s);
+  }
   {
     ProfScope ps(0, s);
     u3d_launch_preprocess_fwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, s);

@@ -57,6 +57,10 @@ struct U3DSource {
   const float* center;  // [B][P][3] (act != 0)
   float offset_scale;
   const float* qnorm;   // [B][4] across-point quaternion column norms (act == 1)
+  // act == 1 and P <= 256 (one workgroup holds the whole set): preprocess_fwd computes the norms itself, publishes them
+  // here for the backward, and clears qdot_zero -- no separate quat_norms launch
+  float* qnorm_out;
+  float* qdot_zero;
 };
 
 // Where per-Gaussian gradients go (same strides as the source; act != 0 chains through the activations).

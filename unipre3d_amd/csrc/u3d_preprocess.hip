@@ -191,6 +191,37 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     __syncthreads();
     lsrc.means = s_rec; lsrc.opac = s_rec + 3; lsrc.scales = s_rec + 4; lsrc.rots = s_rec + 7; lsrc.shs = s_rec + 11;
     lsrc.center = src.center + ((size_t)item * P + i0) * 3;
+    if (src.act == 1 && src.qnorm_out) {
+      // the block holds the whole set: across-point quaternion column norms from the staged records (same summation
+      // order as quat_norms_kernel); the first view slice publishes them for the backward and clears qdot
+      __shared__ float s_qsm[4][4];
+      __shared__ float s_qn[4];
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      if (i < P) {
+        const float* r = s_rec + (size_t)threadIdx.x * C + 7;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += r[k] * r[k];
+      }
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v = a[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) s_qsm[wave][k] = v;
+      }
+      __syncthreads();
+      if (threadIdx.x < 4) {
+        const float n = sqrtf(s_qsm[0][threadIdx.x] + s_qsm[1][threadIdx.x] + s_qsm[2][threadIdx.x] + s_qsm[3][threadIdx.x]);
+        s_qn[threadIdx.x] = n;
+        if (blockIdx.z == 0) {
+          src.qnorm_out[item * 4 + threadIdx.x] = n;
+          if (src.qdot_zero) src.qdot_zero[item * 4 + threadIdx.x] = 0.f;
+        }
+      }
+      __syncthreads();
+      lsrc.qnorm = s_qn - item * 4;
+    }
   }
   uint32_t touched_local[1] = {0};
   (void)touched_local;
