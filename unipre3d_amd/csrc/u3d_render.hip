@@ -77,8 +77,10 @@ __device__ __forceinline__ float min_099(float a) {   // fminf(0.99f, a) without
 //     reduction  my = dy m0, mxy = dy mx, myy = dy my;
 //   * the half-row and row levels use DPP bank masks to deposit two values into one register per instruction pair
 //     (9-10 values -> 5 -> 3 registers), and the four rows of the wave meet in three LDS float adds.
-constexpr int BWD_PART_STRIDE = U3D_NACC * U3D_WAVE + 16;   // floats per tile slot (+ row count, 64-B aligned)
-constexpr int BWD_REDUCE_SPLIT = 8;                          // workgroups per view in bwd_reduce_kernel
+constexpr int BWD_PART_STRIDE = U3D_PART_STRIDE;   // floats per tile: [64 positions][12], the LDS rows as they are
+// bwd_reduce_kernel: workgroups per view.  The slices of a view meet in f64 atomics (cost ~ slices), the tile chain of a
+// slice is latency-bound (cost ~ tiles per slice): ~128 tiles per slice measured best (C2: 10.4 us with 2 slices, 17 with 8).
+static inline int bwd_reduce_split(int T) { const int s = (T + 64) / 128; return s < 1 ? 1 : (s > 32 ? 32 : s); }
 constexpr int TILE_WAVES = 1;   // tiles per workgroup: one (finer-grained dispatch measured 8 % faster than four)
 
 struct TileLds {
@@ -207,7 +209,7 @@ __device__ __forceinline__ T moment_to_acc(int k, const T* m, float a, float b, 
 //     m0 = sum q, mx = sum q dx, my = sum q dy, mxx = sum q dx^2, mxy = sum q dx dy, myy = sum q dy^2.
 // Cross-tile accumulation without atomics in the common case: the first 64 positions of the view's sorted list -- where
 // the reference's large, fairly opaque splats put essentially all contributions -- are written per tile to
-// part[tile][component][position] (plain coalesced stores) and summed over the tiles in a FIXED order, in f64, by
+// part[tile][position][12] (the LDS rows as they are, only the rows the tile touched) and summed over the tiles in a FIXED order, in f64, by
 // bwd_reduce_kernel.  Only sorted positions >= 64 (sparse / semi-transparent scenes) fall back to f64 global atomics,
 // whose ordering does not show at fp32 output precision (the original: one fp32 atomic per pixel and component).
 //   Tr = T_final, Rk = T_final (bg . dL/dC), lim = exclusive sorted-position limit per pixel (0: pixel takes no part).
@@ -217,7 +219,7 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
                                               const uint32_t (&lim)[4], float (&Tr)[4], float (&Rk)[4],
                                               const float (&dp0)[4], const float (&dp1)[4], const float (&dp2)[4],
                                               const float (&dinv)[4], float half_w, float half_h, size_t NG,
-                                              double* __restrict__ acc, float* __restrict__ pt) {
+                                              double* __restrict__ acc, float* __restrict__ pt, uint32_t* __restrict__ pcnt) {
   constexpr int NK = HAS_INVD ? U3D_NACC : U3D_NACC - 1;
   const bool row_lane = (lane & 3) == 0, first_lane = (lane & 15) == 0;
   const int bank = (lane >> 2) & 3;
@@ -372,14 +374,13 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
       __builtin_amdgcn_wave_barrier();
     }
   }
-  // positions 0..63 of this tile: plain coalesced stores of the raw moments (only the rows this tile can have touched:
-  // positions < min(wmax, 64); the count is the last word of the slot)
+  // positions 0..63 of this tile: the LDS rows (raw moments) of the positions this tile can have touched, 48 B per lane
   const uint32_t cnt = min(wmax, (uint32_t)U3D_WAVE);
   if ((uint32_t)lane < cnt) {
 #pragma unroll
-    for (int k = 0; k < NK; ++k) pt[k * U3D_WAVE + lane] = reinterpret_cast<const float*>(&L.acc[lane][0])[k];
+    for (int k = 0; k < 3; ++k) reinterpret_cast<float4*>(pt)[lane * 3 + k] = L.acc[lane][k];
   }
-  if (lane == 0) reinterpret_cast<uint32_t*>(pt)[U3D_NACC * U3D_WAVE] = cnt;
+  if (lane == 0) *pcnt = cnt;
 }
 
 // image rows: 4 consecutive pixels per lane (one 16-byte access when W % 4 == 0)
@@ -415,7 +416,7 @@ __device__ __forceinline__ void loss_seed(const U3DLoss& loss, const float* __re
 }
 
 #define U3D_TILE_PROLOGUE(NWAVES)                                                                       \
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;                                        \
+  const int tid = threadIdx.x, wave = (NWAVES) == 1 ? 0 : tid >> 6, lane = tid & 63; /* 1: all ids scalar */ \
   const uint32_t lid = u3d_xcd_remap(blockIdx.x, nblocks) * (uint32_t)(NWAVES) + (uint32_t)wave;        \
   if (lid >= ntiles_total) return; /* whole wave leaves; there is no workgroup barrier below */         \
   const int view = (int)(lid / T);                                                                      \
@@ -523,7 +524,8 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
     Rk[k] = Tr[k] * (bg[0] * dp0[k] + bg[1] * dp1[k] + bg[2] * dp2[k]);   // T_final * (bg . dL/dC)
   }
   tile_backward<HAS_INVD>(L, G, lane, tile_last[lid], -1, 0ull, pyf, pxf, lim, Tr, Rk, dp0, dp1, dp2, dinv, 0.5f * (float)W,
-                          0.5f * (float)H, NG, acc, part + (size_t)lid * BWD_PART_STRIDE);
+                          0.5f * (float)H, NG, acc, part + (size_t)lid * BWD_PART_STRIDE,
+                          reinterpret_cast<uint32_t*>(part + (size_t)ntiles_total * BWD_PART_STRIDE) + lid);
 }
 
 // ---- forward + backward in ONE kernel (training step of the fused render-loss path) -----------------
@@ -578,24 +580,31 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fb_wave_kernel(
   if (lane == 0) loss.partial[lid] = e;
 
   tile_backward<false>(L, G, lane, F.wlast, F.staged, F.staged_bal, pyf, pxf, F.stop_pos, F.Tr, Rk, dp0, dp1, dp2, dinv,
-                       0.5f * (float)W, 0.5f * (float)H, NG, acc, part + (size_t)lid * BWD_PART_STRIDE);
+                       0.5f * (float)W, 0.5f * (float)H, NG, acc, part + (size_t)lid * BWD_PART_STRIDE,
+                          reinterpret_cast<uint32_t*>(part + (size_t)ntiles_total * BWD_PART_STRIDE) + lid);
 }
 
-// acc[k][view*P + sorted_id[sp]] += sum over a slice of the view's tiles (ascending) of part[tile][k][sp], in f64;
-// the BWD_REDUCE_SPLIT slices of a view meet in an f64 atomic (order-insensitive at fp32 output precision).
-__global__ __launch_bounds__(U3D_NACC * U3D_WAVE) void bwd_reduce_kernel(int P, int T, int NK, size_t NG, float half_w, float half_h,
-                                                                        const uint32_t* __restrict__ sorted_id,
-                                                                        const float4* __restrict__ conic_op,
-                                                                        const float* __restrict__ part,
-                                                                        double* __restrict__ acc, int n_loss,
-                                                                        const float* __restrict__ loss_partial, float inv_count,
-                                                                        float* __restrict__ loss_out) {
-  __shared__ double s_sum[U3D_NACC][U3D_WAVE];
-  if (blockIdx.y == BWD_REDUCE_SPLIT) {
+// acc[k][view*P + sorted_id[sp]] += sum over a slice of the view's tiles (ascending) of part[tile][sp][k], in f64;
+// the nsplit slices of a view meet in an f64 atomic (order-insensitive at fp32 output precision).
+// One thread per (position, component) element of a tile's [64][12] block, so a tile is one contiguous read; only the
+// positions some tile of the slice touched (cmax, usually ~20 of 64) are read at all.
+constexpr int REDUCE_THREADS = U3D_WAVE * 12;
+#define RU 32   // tiles in flight per thread
+__global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T, int NK, int nsplit, size_t NG, float half_w, float half_h,
+                                                                   const uint32_t* __restrict__ sorted_id,
+                                                                   const float4* __restrict__ conic_op,
+                                                                   const float* __restrict__ part,
+                                                                   const uint32_t* __restrict__ part_cnt,
+                                                                   double* __restrict__ acc, int n_loss,
+                                                                   const float* __restrict__ loss_partial, float inv_count,
+                                                                   float* __restrict__ loss_out) {
+  __shared__ double s_sum[U3D_WAVE][12];
+  __shared__ uint32_t s_cmax;
+  if ((int)blockIdx.y == nsplit) {
     // extra row of the grid: fixed-order sum of the per-tile loss partials (replaces a separate launch)
     if (blockIdx.x != 0) return;
     float* sm = reinterpret_cast<float*>(&s_sum[0][0]);
-    constexpr int NT = U3D_NACC * U3D_WAVE;
+    constexpr int NT = REDUCE_THREADS;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int i = threadIdx.x;
     for (; i + 3 * NT < n_loss; i += 4 * NT) {
@@ -613,46 +622,54 @@ __global__ __launch_bounds__(U3D_NACC * U3D_WAVE) void bwd_reduce_kernel(int P, 
     }
     return;
   }
-  const int view = blockIdx.x, k = threadIdx.x >> 6, sp = threadIdx.x & 63;
+  const int view = blockIdx.x, sp = threadIdx.x / 12, k = threadIdx.x - sp * 12;
+  const int per = (T + nsplit - 1) / nsplit;
+  const int t0 = blockIdx.y * per, t1 = min(T, t0 + per);
+  const uint32_t* cnt = part_cnt + (size_t)view * T;
+  if (threadIdx.x == 0) s_cmax = 0u;
+  __syncthreads();
+  {
+    uint32_t c = 0u;
+    for (int t = t0 + (int)threadIdx.x; t < t1; t += REDUCE_THREADS) c = max(c, cnt[t]);
+    if (c != 0u) atomicMax(&s_cmax, c);
+  }
+  __syncthreads();
+  const uint32_t cmax = s_cmax;
+  if (cmax == 0u) return;
   double a = 0.0;
-  if (k < NK) {
-    const int per = (T + BWD_REDUCE_SPLIT - 1) / BWD_REDUCE_SPLIT;
-    const int t0 = blockIdx.y * per, t1 = min(T, t0 + per);
-    const float* base = part + (size_t)view * T * BWD_PART_STRIDE;
-    // loads are unconditional (rows a tile did not write hold stale bytes, discarded by the select) so that a whole group
-    // of tiles is in flight at once; accumulation order stays ascending in t within each of the two chains
+  if (k < NK && (uint32_t)sp < cmax) {
+    const float* base = part + (size_t)view * T * BWD_PART_STRIDE + threadIdx.x;
+    // loads are unconditional below cmax (rows a tile did not write hold stale bytes, discarded by the select) so that a
+    // whole group of tiles is in flight at once; accumulation order stays ascending in t within each of the two chains
     double a0 = 0.0, a1 = 0.0;
     int t = t0;
-    for (; t + 7 < t1; t += 8) {
-      float v[8];
-      uint32_t c[8];
+    for (; t + RU - 1 < t1; t += RU) {
+      float v[RU];
+      uint32_t c[RU];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float* pu = base + (size_t)(t + u) * BWD_PART_STRIDE;
-        c[u] = reinterpret_cast<const uint32_t*>(pu)[U3D_NACC * U3D_WAVE];
-        v[u] = pu[k * U3D_WAVE + sp];
+      for (int u = 0; u < RU; ++u) {
+        c[u] = cnt[t + u];
+        v[u] = base[(size_t)(t + u) * BWD_PART_STRIDE];
       }
 #pragma unroll
-      for (int u = 0; u < 8; u += 2) {
+      for (int u = 0; u < RU; u += 2) {
         a0 += (uint32_t)sp < c[u] ? (double)v[u] : 0.0;
         a1 += (uint32_t)sp < c[u + 1] ? (double)v[u + 1] : 0.0;
       }
     }
     for (; t < t1; ++t) {
-      const float* p0 = base + (size_t)t * BWD_PART_STRIDE;
-      const uint32_t c0 = reinterpret_cast<const uint32_t*>(p0)[U3D_NACC * U3D_WAVE];
-      const float v0 = p0[k * U3D_WAVE + sp];
-      a0 += (uint32_t)sp < c0 ? (double)v0 : 0.0;
+      const float v0 = base[(size_t)t * BWD_PART_STRIDE];
+      a0 += (uint32_t)sp < cnt[t] ? (double)v0 : 0.0;
     }
     a = a0 + a1;
   }
   // raw moment sums of this slice -> accumulator values (linear, so slices can be converted independently)
-  s_sum[k][sp] = a;
+  s_sum[sp][k] = a;
   __syncthreads();
-  if (k >= NK) return;
+  if (k >= NK || (uint32_t)sp >= cmax) return;
   double m[U3D_NACC];
 #pragma unroll
-  for (int j = 0; j < U3D_NACC; ++j) m[j] = j < NK ? s_sum[j][sp] : 0.0;
+  for (int j = 0; j < U3D_NACC; ++j) m[j] = j < NK ? s_sum[sp][j] : 0.0;
   bool any = false;
 #pragma unroll
   for (int j = 0; j < U3D_NACC; ++j) any = any || m[j] != 0.0;
@@ -711,9 +728,11 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
   hipLaunchKernelGGL(render_fb_wave_kernel, dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
                      tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
                      acc, part, loss);
-  hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, BWD_REDUCE_SPLIT + 1), dim3(U3D_NACC * U3D_WAVE), 0, s,
-                     d.P, T, U3D_NACC - 1, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id, b.conic_op, part,
-                     acc, (int)ntiles, loss.partial, loss.inv_count, loss_out);
+  const int nsplit = bwd_reduce_split(T);
+  hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, nsplit + 1), dim3(REDUCE_THREADS), 0, s,
+                     d.P, T, U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id, b.conic_op, part,
+                     reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, (int)ntiles, loss.partial,
+                     loss.inv_count, loss_out);
 }
 
 void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, const float* dL_dcolor,
@@ -734,7 +753,9 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
     hipLaunchKernelGGL(render_bwd_wave_kernel<false>, dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height,
                        d.image_width, tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg,
                        dL_dcolor, dL_dinvdepth, b.final_T, b.n_contrib, b.tile_last, acc, part, out_color, loss);
-  hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, BWD_REDUCE_SPLIT), dim3(U3D_NACC * U3D_WAVE), 0, s,
-                     d.P, T, invd ? U3D_NACC : U3D_NACC - 1, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id,
-                     b.conic_op, part, acc, 0, nullptr, 0.f, nullptr);
+  const int nsplit = bwd_reduce_split(T);
+  hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, nsplit), dim3(REDUCE_THREADS), 0, s,
+                     d.P, T, invd ? U3D_NACC : U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id,
+                     b.conic_op, part, reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, 0, nullptr, 0.f,
+                     nullptr);
 }
