@@ -221,7 +221,7 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
                                               const float (&dinv)[4], float half_w, float half_h, size_t NG,
                                               double* __restrict__ acc, float* __restrict__ pt, uint32_t* __restrict__ pcnt) {
   constexpr int NK = HAS_INVD ? U3D_NACC : U3D_NACC - 1;
-  const bool row_lane = (lane & 3) == 0, first_lane = (lane & 15) == 0;
+  const bool row_lane = (lane & 3) == 0;
   const int bank = (lane >> 2) & 3;
   const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
   for (int b = nb - 1; b >= 0; --b) {
@@ -347,12 +347,11 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
       // the four 16-lane rows meet in LDS: batch 0 is indexed by sorted position (merged across tiles by
       // bwd_reduce_kernel), later batches by compaction slot
       float* sl = reinterpret_cast<float*>(&L.acc[b == 0 ? (int)pos - 1 : j][0]);
-      if (row_lane) {
+      if (row_lane) {   // (per-lane addresses on purpose: a wave-uniform one makes hipcc serialise the add over the lanes)
         atomicAdd(sl + bank, mx);
         atomicAdd(sl + 4 + bank, myy);
-        if (HAS_INVD && bank < 2) atomicAdd(sl + 8 + bank, g_b);
+        if (bank < (HAS_INVD ? 2 : 1)) atomicAdd(sl + 8 + bank, g_b);
       }
-      if (!HAS_INVD && first_lane) atomicAdd(sl + 8, g_b);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
