@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--two-pass", action="store_true", help="separate forward and backward launch sequences (images kept)")
     ap.add_argument("--unfused", action="store_true", help="torch activations + torch loss around the batched operator")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end stand-in region")
+    ap.add_argument("--hot-only", action="store_true", help="primary timed region only (profiling runs: keeps the per-kernel averages clean)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     a = ap.parse_args()
@@ -208,6 +209,13 @@ def main():
 
     # timed region: HIP events only around the dominant tile kernel(s) (each recorded scope idles the stream ~4-5 us);
     # the small kernels are timed in a short separate pass and merged into the per-kernel table below
+    # untimed pre-warm before the contractual W warmup steps: a fresh box pages the libraries in and ramps its clocks during
+    # the first second of work (a first-process run measured 20 % slower than its own repeat without this)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 1.0:
+        for _ in range(20):
+            hot_step()
+        torch.cuda.synchronize()
     elapsed, prof, loss = timed(hot_step, True)
     _, prof_small, _ = timed(hot_step, True, steps=10, warmup=2, kinds=("preprocess_fwd", "depth_sort", "preprocess_bwd"))
     prof = {k: (prof[k] if prof[k][1] else prof_small[k]) for k in prof}
@@ -215,6 +223,8 @@ def main():
     # ---- secondary regions (never `value`); a failure here must not lose the primary result ----
     extras = {}
     try:
+        if a.hot_only:
+            raise RuntimeError("skipped (--hot-only)")
         ddp_head = dp.create_ddp_model(model, sync_bn=False)
         opt = torch.optim.AdamW(ddp_head.parameters(), lr=1e-4, eps=1e-15, fused=True)  # train_network.py:156-158 (group lr 1e-4)
         el, _, l = timed(lambda: step.train_step(ddp_head, feats, batch, opt, H, W, 0, loss_kind, fused=not a.unfused), False)
@@ -224,7 +234,7 @@ def main():
                     + "NaN-check/clip_grad_norm + AdamW"}
     except Exception as e:  # noqa: BLE001
         extras["train_step_with_head"] = {"error": repr(e)[:300]}
-    if level == "object" and not a.no_e2e:
+    if level == "object" and not a.no_e2e and not a.hot_only:
         try:
             extras["train_step_e2e_standin"] = e2e_region(a, batch, dev, world, rank, B, V, H, W, loss_kind, timed)
         except Exception as e:  # noqa: BLE001
