@@ -1,0 +1,45 @@
+"""Seeded shape fuzz of the operator path against the CPU oracle: ragged image sizes (W % 4 != 0 takes the scalar image path,
+W % 16 != 0 / H % 16 != 0 partial tiles), P around the 64-entry batch and 256-key sort boundaries, both levels, all SH
+degrees, compact and large splats.  Same tolerance as test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from scenes import DIFF_KEYS, cotangents, scene, to_numpy
+from test_gpu_parity import TOL, _run_gpu, near
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(n=24, seed=20260928):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        P = int(rng.choice([1, 2, 7, 63, 64, 65, 100, 129, 255, 256, 257, 400]))
+        H = int(rng.integers(1, 72))
+        W = int(rng.integers(1, 72))
+        out.append((P, H, W, ("object", "scene")[i % 2], bool(rng.integers(0, 2)), int(rng.integers(0, 4)), 100 + i))
+    return out
+
+
+@pytest.mark.parametrize("P,H,W,level,compact,deg,seed", _cases())
+def test_fuzz_forward_backward_vs_oracle(oracle_mod, P, H, W, level, compact, deg, seed):
+    sc = scene(P, H, W, seed, level, compact, deg)
+    dcol, dinv = cotangents(H, W, seed=seed)
+    color, invd, radii, g = _run_gpu(sc, dcol, dinv)
+    r32 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc))
+    r64 = oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
+    assert np.array_equal(radii, r32.radii) or np.array_equal(radii, r64.radii)
+    assert near(color, r32.color, r64.color) and near(invd, r32.invdepth, r64.invdepth)
+    g32 = oracle_mod.backward(r32, dcol.numpy(), dinv.numpy())
+    g64 = oracle_mod.backward(r64, dcol.numpy().astype(np.float64), dinv.numpy().astype(np.float64))
+    for k in DIFF_KEYS + ("means2D",):
+        a = g[k].reshape(g32[k].shape)
+        if not np.any(g32[k]) and not np.any(g64[k]):
+            assert not np.any(a), k
+        else:
+            # ill-conditioned draws (a handful of huge splats): the fp32 restatement itself is up to ~1e-4 from the fp64
+            # arbiter there, so the bar becomes "as close to fp64 as the fp32 restatement is, within 3x"
+            assert near(a, g32[k], g64[k]) or rel_l2(a, g64[k]) < 3 * rel_l2(g32[k], g64[k]), \
+                (k, rel_l2(a, g32[k]), rel_l2(a, g64[k]), rel_l2(g32[k], g64[k]))
