@@ -71,7 +71,14 @@ class _Plan:
         pass
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr():
+    """torch's CURRENT stream on the current device as a hipStream_t (the raw-handle query costs ~0.3 us, the Stream object
+    route ~10 us per call)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
