@@ -416,7 +416,8 @@ __device__ __forceinline__ void loss_seed(const U3DLoss& loss, const float* __re
 
 #define U3D_TILE_PROLOGUE(NWAVES)                                                                       \
   const int tid = threadIdx.x, wave = (NWAVES) == 1 ? 0 : tid >> 6, lane = tid & 63; /* 1: all ids scalar */ \
-  const uint32_t lid = u3d_xcd_remap(blockIdx.x, nblocks) * (uint32_t)(NWAVES) + (uint32_t)wave;        \
+  const uint32_t lid = (NWAVES) == 1 ? u3d_xcd_remap_view(blockIdx.x, (uint32_t)T)                     \
+                                     : u3d_xcd_remap(blockIdx.x, nblocks) * (uint32_t)(NWAVES) + (uint32_t)wave; \
   if (lid >= ntiles_total) return; /* whole wave leaves; there is no workgroup barrier below */         \
   const int view = (int)(lid / T);                                                                      \
   const int tile = (int)lid - view * T;                                                                 \
