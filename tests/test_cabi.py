@@ -99,3 +99,30 @@ def test_product_never_imports_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
     src = open(os.path.join(ROOT, "diff_gaussian_rasterization", "__init__.py")).read()
     assert "oracle" not in src
+
+
+def test_xcd_view_chunk_mapping_is_a_bijection():
+    """Host restatement of `u3d_xcd_remap_view` (unipre3d_amd/csrc/u3d_common.h): workgroup b sits on XCD b % 8; within each
+    view the blocks of one residue class must map, in order, onto one contiguous chunk of that view's tiles, and the whole
+    map must be a bijection for ANY tile count (the kernels index per-tile scratch with it)."""
+    def below(n, c):
+        return (n >> 3) * c + min(n & 7, c)
+
+    def remap(b, T):
+        view = b // T
+        j = b - view * T
+        r = (view * T) & 7
+        m = r + j
+        x = m & 7
+        k = ((m + 7 - x) >> 3) - ((r + 7 - x) >> 3)
+        return view * T + (below(r + T, x) - below(r, x)) + k
+
+    for T in (1, 2, 3, 7, 8, 9, 12, 15, 16, 20, 63, 64, 70, 256, 1200):
+        for nv in (1, 3, 8):
+            out = [remap(b, T) for b in range(nv * T)]
+            assert sorted(out) == list(range(nv * T)), (T, nv)
+            for v in range(nv):
+                for x in range(8):
+                    tiles = [out[b] for b in range(v * T, (v + 1) * T) if b % 8 == x]
+                    assert tiles == list(range(tiles[0], tiles[0] + len(tiles))) if tiles else True   # contiguous, in order
+                    assert all(v * T <= t < (v + 1) * T for t in tiles)
