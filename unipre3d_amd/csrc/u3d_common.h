@@ -101,7 +101,7 @@ static inline size_t u3d_carve_fused(const u3d_raster_desc& d, void* base, U3DFu
   return 2 * a + (((NV * T * sizeof(float)) + 255) & ~(size_t)255) + 256;
 }
 
-#define U3D_PART_STRIDE (U3D_WAVE * 12)   // floats per tile in the partial-row buffer
+#define U3D_PART_STRIDE (U3D_WAVE * 10)   // floats per tile in the partial-row buffer
 static inline size_t u3d_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // single source of truth for carving; base pointers may be null when only sizes are wanted
@@ -149,11 +149,11 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
   L.image_bytes = o > 0 ? o : 256;
 #undef CARVE
   // f64 accumulators: global_atomic_add_f64 makes the cross-tile sum order-insensitive at fp32 output precision
-  // + per-tile partials of the first 64 sorted positions: [NV*T][64][12] floats + [NV*T] row counts (see tile_backward)
+  // + per-tile partials of the first 64 sorted positions: [NV*T][64][10] floats + [NV*T] row counts (see tile_backward)
   L.acc_bytes = u3d_align(sizeof(double) * U3D_NACC * (NG > 0 ? NG : 1));
   {
     const size_t Tn = (size_t)((d.image_width + U3D_TILE - 1) / U3D_TILE) * ((d.image_height + U3D_TILE - 1) / U3D_TILE);
-    // per tile: 64 sorted positions x 12 floats (the LDS rows as they are) + a compact count array
+    // per tile: 64 sorted positions x 10 floats (the LDS rows as they are) + a compact count array
     L.backward_bytes = L.acc_bytes + u3d_align(sizeof(float) * U3D_PART_STRIDE * (NV * Tn > 0 ? NV * Tn : 1)) +
                        u3d_align(sizeof(uint32_t) * (NV * Tn > 0 ? NV * Tn : 1));
   }

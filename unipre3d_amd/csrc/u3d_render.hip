@@ -77,17 +77,18 @@ __device__ __forceinline__ float min_099(float a) {   // fminf(0.99f, a) without
 //     reduction  my = dy m0, mxy = dy mx, myy = dy my;
 //   * the half-row and row levels use DPP bank masks to deposit two values into one register per instruction pair
 //     (9-10 values -> 5 -> 3 registers), and the four rows of the wave meet in three LDS float adds.
-constexpr int BWD_PART_STRIDE = U3D_PART_STRIDE;   // floats per tile: [64 positions][12], the LDS rows as they are
+constexpr int BWD_PART_STRIDE = U3D_PART_STRIDE;   // floats per tile: [64 positions][10], the LDS rows as they are
 // bwd_reduce_kernel: workgroups per view.  The slices of a view meet in f64 atomics (cost ~ slices), the tile chain of a
 // slice is latency-bound (cost ~ tiles per slice): ~128 tiles per slice measured best (C2: 10.4 us with 2 slices, 17 with 8).
 static inline int bwd_reduce_split(int T) { const int s = (T + 64) / 128; return s < 1 ? 1 : (s > 32 ? 32 : s); }
 constexpr int TILE_WAVES = 1;   // tiles per workgroup: one (finer-grained dispatch measured 8 % faster than four)
 
-struct TileLds {
-  float4* A;          // [64] x, y, a' = -log2e/2 a, b' = -log2e b
-  float4* B;          // [64] c' = -log2e/2 c, opacity, 1/depth, pos (bits)
-  float4* C;          // [64] r, g, b, id (bits)
-  float4 (*acc)[3];   // [64][3] per slot: {mx,my,mxx,mxy} {myy,m0,r,g} {b,d,-,-}   (backward only)
+struct TileLds {   // wave-private; 2560 B of staged entries + 2560 B of gradient rows = 5 KB per wave -> 32 waves per CU
+  float4* P0;          // [64] x, y, a' = -log2e/2 a, b' = -log2e b
+  float4* P1;          // [64] c' = -log2e/2 c, opacity, r, g
+  float2* P2;          // [64] b, pos (bits)
+  float* D;            // [64] 1/depth (only the kernels that carry inverse depth)
+  float (*acc)[10];    // [64] per slot: mx, my, mxx, mxy, myy, m0, r, g, b, d   (backward only)
 };
 struct TileGeom {
   const uint32_t* sorted_id; const uint2* sorted_rect; const float2* xy; const float4* conic_op; const float4* rgbd;
@@ -95,6 +96,7 @@ struct TileGeom {
 };
 
 // stage sorted entries [b*64, b*64+64) limited to `limit`; returns the hit ballot (compaction keeps the order)
+template <bool DEPTH>
 __device__ __forceinline__ lanemask_t tile_stage(const TileLds& L, const TileGeom& G, int lane, int b, uint32_t limit) {
   const uint32_t s = (uint32_t)b * U3D_WAVE + (uint32_t)lane;
   bool hit = false;
@@ -102,14 +104,14 @@ __device__ __forceinline__ lanemask_t tile_stage(const TileLds& L, const TileGeo
   const lanemask_t bal = __ballot(hit);
   if (hit) {
     const uint32_t o = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-    const uint32_t id = G.sorted_id[G.vbase + s];
-    const size_t g = G.vbase + id;
+    const size_t g = G.vbase + G.sorted_id[G.vbase + s];
     const float2 m = G.xy[g];
     const float4 co = G.conic_op[g];
     const float4 cd = G.rgbd[g];
-    L.A[o] = make_float4(m.x, m.y, (-0.5f * LOG2E) * co.x, -LOG2E * co.y);
-    L.B[o] = make_float4((-0.5f * LOG2E) * co.z, co.w, 1.0f / cd.w, __uint_as_float(s + 1u));
-    L.C[o] = make_float4(cd.x, cd.y, cd.z, __uint_as_float(id));
+    L.P0[o] = make_float4(m.x, m.y, (-0.5f * LOG2E) * co.x, -LOG2E * co.y);
+    L.P1[o] = make_float4((-0.5f * LOG2E) * co.z, co.w, cd.x, cd.y);
+    L.P2[o] = make_float2(cd.z, __uint_as_float(s + 1u));
+    if (DEPTH) L.D[o] = 1.0f / cd.w;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -141,21 +143,22 @@ __device__ __forceinline__ void tile_forward(const TileLds& L, const TileGeom& G
   bool wave_done = false;
   const int nbf = (int)((nv + U3D_WAVE - 1) / U3D_WAVE);
   for (int b = 0; b < nbf && !wave_done; ++b) {
-    const lanemask_t bal = tile_stage(L, G, lane, b, nv);
+    const lanemask_t bal = tile_stage<DEPTH>(L, G, lane, b, nv);
     F.staged = b; F.staged_bal = bal;
     const int total = __popcll(bal);
     for (int j = 0; j < total; ++j) {
-      const float4 A = L.A[j];
-      const float4 B = L.B[j];
-      const float4 Cc = L.C[j];
+      const float4 A = L.P0[j];
+      const float4 Q = L.P1[j];
+      const float2 R = L.P2[j];
+      const float invd = DEPTH ? L.D[j] : 0.f;
       const float dy = A.y - pyf;
-      const float bdy = A.w * dy, cdy2 = (B.x * dy) * dy;
+      const float bdy = A.w * dy, cdy2 = (Q.x * dy) * dy;
       lanemask_t contrib = 0ull, stopped = 0ull, m_stop[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {   // one basic block: the four pixels' dependency chains interleave
         const float dx = A.x - pxf[k];
         const float pw = fmaf(fmaf(A.z, dx, bdy), dx, cdy2);
-        const float alpha = min_099(B.y * __builtin_amdgcn_exp2f(pw));
+        const float alpha = min_099(Q.y * __builtin_amdgcn_exp2f(pw));
         const lanemask_t m_ok = __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE) & __builtin_amdgcn_fcmpf(alpha, amin[k], U3D_FCMP_OGE);
         const float w = alpha * F.Tr[k];
         const float test_T = F.Tr[k] - w;          // T (1 - alpha)
@@ -163,10 +166,10 @@ __device__ __forceinline__ void tile_forward(const TileLds& L, const TileGeom& G
         const lanemask_t m_c = m_ok & ~m_lt;
         m_stop[k] = m_ok & m_lt;
         const float we = mask_sel0(m_c, w);      // blended weight, 0 for pixels that skip this Gaussian
-        F.C0[k] = fmaf(Cc.x, we, F.C0[k]);
-        F.C1[k] = fmaf(Cc.y, we, F.C1[k]);
-        F.C2[k] = fmaf(Cc.z, we, F.C2[k]);
-        if (DEPTH) F.Dv[k] = fmaf(B.z, we, F.Dv[k]);
+        F.C0[k] = fmaf(Q.z, we, F.C0[k]);
+        F.C1[k] = fmaf(Q.w, we, F.C1[k]);
+        F.C2[k] = fmaf(R.x, we, F.C2[k]);
+        if (DEPTH) F.Dv[k] = fmaf(invd, we, F.Dv[k]);
         F.Tr[k] -= we;
         contrib |= m_c;
         stopped |= m_stop[k];
@@ -176,13 +179,13 @@ __device__ __forceinline__ void tile_forward(const TileLds& L, const TileGeom& G
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           amin[k] = mask_sel(m_stop[k], 2.f, amin[k]);
-          F.stop_pos[k] = __float_as_uint(mask_sel(m_stop[k], B.w, __uint_as_float(F.stop_pos[k])));
+          F.stop_pos[k] = __float_as_uint(mask_sel(m_stop[k], R.y, __uint_as_float(F.stop_pos[k])));
         }
         const bool all_done = amin[0] > 1.f && amin[1] > 1.f && amin[2] > 1.f && amin[3] > 1.f;
         if (__ballot(!all_done) == 0ull) { wave_done = true; break; }
       }
     }
-    if (blast == b) F.wlast = __builtin_amdgcn_readfirstlane(__float_as_uint(L.B[jlast].w));
+    if (blast == b) F.wlast = __builtin_amdgcn_readfirstlane(__float_as_uint(L.P2[jlast].y));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -209,7 +212,7 @@ __device__ __forceinline__ T moment_to_acc(int k, const T* m, float a, float b, 
 //     m0 = sum q, mx = sum q dx, my = sum q dy, mxx = sum q dx^2, mxy = sum q dx dy, myy = sum q dy^2.
 // Cross-tile accumulation without atomics in the common case: the first 64 positions of the view's sorted list -- where
 // the reference's large, fairly opaque splats put essentially all contributions -- are written per tile to
-// part[tile][position][12] (the LDS rows as they are, only the rows the tile touched) and summed over the tiles in a FIXED order, in f64, by
+// part[tile][position][10] (the LDS rows as they are, only the rows the tile touched) and summed over the tiles in a FIXED order, in f64, by
 // bwd_reduce_kernel.  Only sorted positions >= 64 (sparse / semi-transparent scenes) fall back to f64 global atomics,
 // whose ordering does not show at fp32 output precision (the original: one fp32 atomic per pixel and component).
 //   Tr = T_final, Rk = T_final (bg . dL/dC), lim = exclusive sorted-position limit per pixel (0: pixel takes no part).
@@ -226,24 +229,25 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
   const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
   for (int b = nb - 1; b >= 0; --b) {
     lanemask_t bal = staged_bal;
-    if (b != staged) { bal = tile_stage(L, G, lane, b, wmax); staged = b; staged_bal = bal; }
+    if (b != staged) { bal = tile_stage<HAS_INVD>(L, G, lane, b, wmax); staged = b; staged_bal = bal; }
     // entries of this batch with pos <= wmax (the compaction keeps positions ascending)
     const uint32_t lm = wmax - (uint32_t)b * U3D_WAVE;
     const int total = lm >= U3D_WAVE ? __popcll(bal) : __popcll(bal & ((1ull << lm) - 1ull));
     for (int j = total - 1; j >= 0; --j) {
-      const float4 A = L.A[j];
-      const float4 B = L.B[j];
-      const float4 Cc = L.C[j];
-      const uint32_t pos = __float_as_uint(B.w);
+      const float4 A = L.P0[j];
+      const float4 Q = L.P1[j];
+      const float2 R = L.P2[j];
+      const float invd = HAS_INVD ? L.D[j] : 0.f;
+      const uint32_t pos = __float_as_uint(R.y);
       const float dy = A.y - pyf;
-      const float bdy = A.w * dy, cdy2 = (B.x * dy) * dy;
+      const float bdy = A.w * dy, cdy2 = (Q.x * dy) * dy;
       float dx[4], ae[4];
       lanemask_t any = 0ull;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         dx[k] = A.x - pxf[k];
         const float pw = fmaf(fmaf(A.z, dx[k], bdy), dx[k], cdy2);
-        const float araw = B.y * __builtin_amdgcn_exp2f(pw);   // opacity * G (alpha before the 0.99 clamp)
+        const float araw = Q.y * __builtin_amdgcn_exp2f(pw);   // opacity * G (alpha before the 0.99 clamp)
         const lanemask_t m = __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE) & __builtin_amdgcn_fcmpf(araw, ALPHA_MIN, U3D_FCMP_OGE) &
                              __builtin_amdgcn_uicmp(pos, lim[k], U3D_ICMP_ULT);
         any |= m;
@@ -259,8 +263,8 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
         const float Tn = Tr[k] * rc;            // T in front of this Gaussian
         const float w = alpha * Tn;
         Tr[k] = Tn;
-        float cdp = fmaf(Cc.z, dp2[k], fmaf(Cc.y, dp1[k], Cc.x * dp0[k]));
-        if (HAS_INVD) cdp = fmaf(B.z, dinv[k], cdp);
+        float cdp = fmaf(R.x, dp2[k], fmaf(Q.w, dp1[k], Q.z * dp0[k]));
+        if (HAS_INVD) cdp = fmaf(invd, dinv[k], cdp);
         const float dL_dalpha = fmaf(Tn, cdp, -(Rk[k] * rc));
         Rk[k] = fmaf(w, cdp, Rk[k]);
         const float q = ae[k] * dL_dalpha;    // dL/dG * G
@@ -346,7 +350,7 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
                      : "v"(my), "v"(mxy), "v"(m0), "v"(g_g));
       // the four 16-lane rows meet in LDS: batch 0 is indexed by sorted position (merged across tiles by
       // bwd_reduce_kernel), later batches by compaction slot
-      float* sl = reinterpret_cast<float*>(&L.acc[b == 0 ? (int)pos - 1 : j][0]);
+      float* sl = &L.acc[b == 0 ? (int)pos - 1 : j][0];
       if (row_lane) {   // (per-lane addresses on purpose: a wave-uniform one makes hipcc serialise the add over the lanes)
         atomicAdd(sl + bank, mx);
         atomicAdd(sl + 4 + bank, myy);
@@ -357,10 +361,11 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
     __builtin_amdgcn_wave_barrier();
     if (b > 0) {
       if (lane < total) {
-        const size_t g = G.vbase + __float_as_uint(L.C[lane].w);
-        const float4 m0v = L.acc[lane][0], m1v = L.acc[lane][1], m2v = L.acc[lane][2];
+        const size_t g = G.vbase + G.sorted_id[G.vbase + __float_as_uint(L.P2[lane].y) - 1u];
         const float4 co = G.conic_op[g];
-        const float m[U3D_NACC] = {m0v.x, m0v.y, m0v.z, m0v.w, m1v.x, m1v.y, m1v.z, m1v.w, m2v.x, m2v.y};
+        float m[U3D_NACC];
+#pragma unroll
+        for (int k = 0; k < U3D_NACC; ++k) m[k] = L.acc[lane][k];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
           const float v = moment_to_acc<float>(k, m, co.x, co.y, co.z, co.w, half_w, half_h);
@@ -368,16 +373,16 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
         }
       }
 #pragma unroll
-      for (int k = 0; k < 3; ++k) L.acc[lane][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < 5; ++k) reinterpret_cast<float2*>(&L.acc[lane][0])[k] = make_float2(0.f, 0.f);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
   }
-  // positions 0..63 of this tile: the LDS rows (raw moments) of the positions this tile can have touched, 48 B per lane
+  // positions 0..63 of this tile: the LDS rows (raw moments) of the positions this tile can have touched, 40 B per lane
   const uint32_t cnt = min(wmax, (uint32_t)U3D_WAVE);
   if ((uint32_t)lane < cnt) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) reinterpret_cast<float4*>(pt)[lane * 3 + k] = L.acc[lane][k];
+    for (int k = 0; k < 5; ++k) reinterpret_cast<float2*>(pt)[lane * 5 + k] = reinterpret_cast<const float2*>(&L.acc[lane][0])[k];
   }
   if (lane == 0) *pcnt = cnt;
 }
@@ -444,9 +449,11 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last, U3DLoss loss) {
-  __shared__ float4 sA[TILE_WAVES][U3D_WAVE], sB[TILE_WAVES][U3D_WAVE], sC[TILE_WAVES][U3D_WAVE];
+  __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
+  __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
+  __shared__ float sD[TILE_WAVES][U3D_WAVE];
   U3D_TILE_PROLOGUE(TILE_WAVES);
-  const TileLds L{sA[wave], sB[wave], sC[wave], nullptr};
+  const TileLds L{sP0[wave], sP1[wave], sP2[wave], sD[wave], nullptr};
   TileFwd F;
   tile_forward<true>(L, G, lane, n_vis[view], pyf, pxf, inside, F);
 
@@ -486,12 +493,14 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_dinvdepth, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_last, double* __restrict__ acc,
     float* __restrict__ part, const float* __restrict__ out_color, U3DLoss loss) {
-  __shared__ float4 sA[TILE_WAVES][U3D_WAVE], sB[TILE_WAVES][U3D_WAVE], sC[TILE_WAVES][U3D_WAVE];
-  __shared__ float4 sAcc[TILE_WAVES][U3D_WAVE][3];
+  __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
+  __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
+  __shared__ float sD[TILE_WAVES][HAS_INVD ? U3D_WAVE : 1];
+  __shared__ __attribute__((aligned(8))) float sAcc[TILE_WAVES][U3D_WAVE][10];
   U3D_TILE_PROLOGUE(TILE_WAVES);
-  const TileLds L{sA[wave], sB[wave], sC[wave], sAcc[wave]};
+  const TileLds L{sP0[wave], sP1[wave], sP2[wave], sD[wave], sAcc[wave]};
 #pragma unroll
-  for (int k = 0; k < 3; ++k) sAcc[wave][lane][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < 5; ++k) reinterpret_cast<float2*>(&sAcc[wave][lane][0])[k] = make_float2(0.f, 0.f);
 
   float Tr[4], Rk[4], dp0[4], dp1[4], dp2[4], dinv[4], limf[4];
   uint32_t lim[4];
@@ -539,12 +548,13 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fb_wave_kernel(
     const float2* __restrict__ xy, const float4* __restrict__ conic_op, const float4* __restrict__ rgbd,
     const float* __restrict__ bg, float* __restrict__ out_color, double* __restrict__ acc, float* __restrict__ part,
     U3DLoss loss) {
-  __shared__ float4 sA[TILE_WAVES][U3D_WAVE], sB[TILE_WAVES][U3D_WAVE], sC[TILE_WAVES][U3D_WAVE];
-  __shared__ float4 sAcc[TILE_WAVES][U3D_WAVE][3];
+  __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
+  __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
+  __shared__ __attribute__((aligned(8))) float sAcc[TILE_WAVES][U3D_WAVE][10];
   U3D_TILE_PROLOGUE(TILE_WAVES);
-  const TileLds L{sA[wave], sB[wave], sC[wave], sAcc[wave]};
+  const TileLds L{sP0[wave], sP1[wave], sP2[wave], nullptr, sAcc[wave]};
 #pragma unroll
-  for (int k = 0; k < 3; ++k) sAcc[wave][lane][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < 5; ++k) reinterpret_cast<float2*>(&sAcc[wave][lane][0])[k] = make_float2(0.f, 0.f);
   TileFwd F;
   tile_forward<false>(L, G, lane, n_vis[view], pyf, pxf, inside, F);
 
@@ -586,9 +596,9 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fb_wave_kernel(
 
 // acc[k][view*P + sorted_id[sp]] += sum over a slice of the view's tiles (ascending) of part[tile][sp][k], in f64;
 // the nsplit slices of a view meet in an f64 atomic (order-insensitive at fp32 output precision).
-// One thread per (position, component) element of a tile's [64][12] block, so a tile is one contiguous read; only the
+// One thread per (position, component) element of a tile's [64][10] block, so a tile is one contiguous read; only the
 // positions some tile of the slice touched (cmax, usually ~20 of 64) are read at all.
-constexpr int REDUCE_THREADS = U3D_WAVE * 12;
+constexpr int REDUCE_THREADS = U3D_WAVE * 10;
 #define RU 32   // tiles in flight per thread
 __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T, int NK, int nsplit, size_t NG, float half_w, float half_h,
                                                                    const uint32_t* __restrict__ sorted_id,
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T
                                                                    double* __restrict__ acc, int n_loss,
                                                                    const float* __restrict__ loss_partial, float inv_count,
                                                                    float* __restrict__ loss_out) {
-  __shared__ double s_sum[U3D_WAVE][12];
+  __shared__ double s_sum[U3D_WAVE][10];
   __shared__ uint32_t s_cmax;
   if ((int)blockIdx.y == nsplit) {
     // extra row of the grid: fixed-order sum of the per-tile loss partials (replaces a separate launch)
@@ -622,7 +632,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T
     }
     return;
   }
-  const int view = blockIdx.x, sp = threadIdx.x / 12, k = threadIdx.x - sp * 12;
+  const int view = blockIdx.x, sp = threadIdx.x / 10, k = threadIdx.x - sp * 10;
   const int per = (T + nsplit - 1) / nsplit;
   const int t0 = blockIdx.y * per, t1 = min(T, t0 + per);
   const uint32_t* cnt = part_cnt + (size_t)view * T;
