@@ -43,3 +43,39 @@ def test_fuzz_forward_backward_vs_oracle(oracle_mod, P, H, W, level, compact, de
             # sits up to ~1e-4 from the fp64 arbiter there (measured: restatement 4-8e-5 depending on its thread order, kernels
             # 1.2-1.35e-4 on the rotation gradient of the P=7 draw), so those draws are held to 2e-4 of the deterministic fp64 result
             assert near(a, g32[k], g64[k]) or rel_l2(a, g64[k]) < 2 * TOL, (k, rel_l2(a, g32[k]), rel_l2(a, g64[k]), rel_l2(g32[k], g64[k]))
+
+
+def test_fuzz_fused_paths_agree_on_random_shapes():
+    """60 seeded draws (1-3 items, 1-3 views, images 1..129 px, P from 1 to 5000, both levels, three losses, compact and large
+    splats): the single-pass fused step, the two-pass fused path and the torch-activations + batched-operator + torch-loss
+    chain give the same loss, image and d loss / d head_out.  (L1's gradient is discontinuous where a pixel equals its
+    target, so it is only held to the loss / image bar.)"""
+    from unipre3d_amd import fused, step, synthetic
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    for it in range(60):
+        B, V = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        P = int(rng.choice([1, 3, 17, 63, 64, 65, 128, 200, 256, 257, 300, 511, 700, 1500, 5000]))
+        H, W = int(rng.integers(1, 130)), int(rng.integers(1, 130))
+        level = ("object", "scene")[int(rng.integers(0, 2))]
+        kind = ("focal_l2", "l2", "l1")[int(rng.integers(0, 3))]
+        b = synthetic.make_batch(B, P, V, H, W, level=level, seed=int(rng.integers(0, 1 << 30)), compact=bool(rng.integers(0, 2))).to(dev)
+        res = []
+        for single_pass in (True, False):
+            h = b.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+            loss, img, _ = fused.render_loss_fused(h, b.center, b.world_view, b.full_proj, b.camera_center, b.gt, b.bg, b.fov_deg, H, W,
+                                                   level=level, offset_scale=b.offset_scale, loss_kind=kind, single_pass=single_pass)
+            loss.backward()
+            res.append((loss.detach(), img, h.grad))
+        raw = b.raw.clone().requires_grad_(True)
+        loss_u, img_u = step.render_loss_forward(raw, b, H, W, 0, kind)
+        loss_u.backward()
+        gu = raw.grad.permute(0, 2, 1)
+        tag = (it, B, P, V, H, W, level, kind)
+        assert all(torch.isfinite(x).all().item() for r in res for x in r), tag
+        assert rel_l2(res[0][1].cpu().numpy(), img_u.detach().cpu().numpy()) < 1e-4, tag
+        assert abs(res[0][0].item() - loss_u.item()) <= 1e-5 * max(1.0, abs(loss_u.item())), tag
+        scale = max(gu.abs().max().item(), 1e-30)
+        assert (res[0][2] - res[1][2]).abs().max().item() <= 1e-6 * scale, tag        # same kernels' arithmetic, two schedules
+        if kind != "l1" and gu.abs().sum().item() > 0:
+            assert rel_l2(res[0][2].cpu().numpy(), gu.cpu().numpy()) < 5 * TOL, tag
