@@ -404,6 +404,12 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
       dL_dmeans2D[g * 3] = a[0]; dL_dmeans2D[g * 3 + 1] = a[1]; dL_dmeans2D[g * 3 + 2] = 0.f;
     }
     if (!live) continue;
+    // no tile handed this (view, Gaussian) any gradient (it lies behind the saturation depth of every tile it touches --
+    // the common case: a pixel saturates after a few dozen entries): every term below would be an exact zero
+    bool nz = false;
+#pragma unroll
+    for (int k = 0; k < U3D_NACC; ++k) nz = nz || a[k] != 0.f;
+    if (!nz) continue;
     Cam cam;
     load_cam(cam, viewmatrix, projmatrix, campos, view);
     Ewa e;
