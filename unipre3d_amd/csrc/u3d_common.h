@@ -8,6 +8,9 @@
 #define U3D_TILE 16
 #define U3D_BLOCK 256       // threads per workgroup = 4 wave64 = one 16x16 tile
 #define U3D_WAVE 64
+// set in `clamped` by the gradient reduction for every (view, Gaussian) that received a non-zero row: preprocess_bwd reads the
+// 80 B of accumulators only for those (a pixel saturates after a few dozen entries, so most visible Gaussians get none)
+#define U3D_TOUCHED_BIT 0x80000000u
 #define U3D_NACC 10         // mean2D.xy, conic(a, b/2, c), opacity, rgb, invdepth
 #define U3D_LDS_SORT_MAX 4096  // largest per-view P sorted by one workgroup in LDS
 // keys per workgroup and radix pass (P > U3D_LDS_SORT_MAX): small tiles keep more workgroups in flight (the passes are
@@ -22,7 +25,7 @@ struct U3DBuffers {
   float4* conic_op;   // [NV*P]   conic a,b,c ; opacity * aa
   float4* rgbd;       // [NV*P]   clamped colour, w = depth
   uint2* rect;        // [NV*P]   x: xmin | ymin<<16 ; y: xmax | ymax<<16   (tile units)
-  uint32_t* clamped;  // [NV*P]   bit c set: colour channel c clamped at 0
+  uint32_t* clamped;  // [NV*P]   bit c set: colour channel c clamped at 0; U3D_TOUCHED_BIT: the backward handed it a gradient
   uint32_t* num_rendered;  // [NV] sum of tiles touched (statistics only)
   // binning
   uint32_t* sorted_id;   // [NV*P] Gaussian index (within the set) in front-to-back order

@@ -396,7 +396,8 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
   for (int vk = vslot; vk < (alive ? vpi : 0); vk += 4) {
     const int view = item * vpi + vk;
     const size_t g = (size_t)view * P + i;
-    const bool live = radii[g] > 0;
+    const uint32_t cbits = clamped[g];
+    const bool live = radii[g] > 0 && (cbits & U3D_TOUCHED_BIT) != 0u;   // visible AND handed a gradient by the reduction
     float a[U3D_NACC];
 #pragma unroll
     for (int k = 0; k < U3D_NACC; ++k) a[k] = live ? (float)acc[(size_t)k * NG + g] : 0.f;
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
       const float sum2 = dorig[0] * dorig[0] + dorig[1] * dorig[1] + dorig[2] * dorig[2];
       const float inv = 1.f / sqrtf(sum2);
       const float x = dorig[0] * inv, y = dorig[1] * inv, z = dorig[2] * inv;
-      const uint32_t cb = clamped[g];
+      const uint32_t cb = cbits;
       float ddir[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 3; ++c) {

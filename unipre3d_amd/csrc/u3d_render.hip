@@ -93,6 +93,7 @@ struct TileLds {   // wave-private; 2560 B of staged entries + 2560 B of gradien
 struct TileGeom {
   const uint32_t* sorted_id; const uint2* sorted_rect; const float2* xy; const float4* conic_op; const float4* rgbd;
   size_t vbase; int tx, ty;
+  uint32_t* touched;   // the `clamped` words (U3D_TOUCHED_BIT), backward only
 };
 
 // stage sorted entries [b*64, b*64+64) limited to `limit`; returns the hit ballot (compaction keeps the order)
@@ -366,11 +367,13 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
         float m[U3D_NACC];
 #pragma unroll
         for (int k = 0; k < U3D_NACC; ++k) m[k] = L.acc[lane][k];
+        bool nz = false;
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
           const float v = moment_to_acc<float>(k, m, co.x, co.y, co.z, co.w, half_w, half_h);
-          if (v != 0.f) unsafeAtomicAdd(&acc[(size_t)k * NG + g], (double)v);
+          if (v != 0.f) { unsafeAtomicAdd(&acc[(size_t)k * NG + g], (double)v); nz = true; }
         }
+        if (nz) G.touched[g] |= U3D_TOUCHED_BIT;   // (every writer ORs the same bit into an otherwise constant word)
       }
 #pragma unroll
       for (int k = 0; k < 5; ++k) reinterpret_cast<float2*>(&L.acc[lane][0])[k] = make_float2(0.f, 0.f);
@@ -440,7 +443,7 @@ __device__ __forceinline__ void loss_seed(const U3DLoss& loss, const float* __re
     pxf[k] = (float)(px0 + k);                                                                          \
     inside[k] = px0 + k < W && py < H;                                                                  \
   }                                                                                                     \
-  const TileGeom G{sorted_id, sorted_rect, xy, conic_op, rgbd, (size_t)view * P, tx, ty}
+  const TileGeom G{sorted_id, sorted_rect, xy, conic_op, rgbd, (size_t)view * P, tx, ty, touched}
 
 // ---- forward (operator path): colour, inverse depth, and the state the backward kernel restarts from --------
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
@@ -449,6 +452,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last, U3DLoss loss) {
+  uint32_t* const touched = nullptr;
   __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ float sD[TILE_WAVES][U3D_WAVE];
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_dinvdepth, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_last, double* __restrict__ acc,
-    float* __restrict__ part, const float* __restrict__ out_color, U3DLoss loss) {
+    float* __restrict__ part, const float* __restrict__ out_color, uint32_t* __restrict__ touched, U3DLoss loss) {
   __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ float sD[TILE_WAVES][HAS_INVD ? U3D_WAVE : 1];
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fb_wave_kernel(
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis,
     const float2* __restrict__ xy, const float4* __restrict__ conic_op, const float4* __restrict__ rgbd,
     const float* __restrict__ bg, float* __restrict__ out_color, double* __restrict__ acc, float* __restrict__ part,
-    U3DLoss loss) {
+    uint32_t* __restrict__ touched, U3DLoss loss) {
   __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ __attribute__((aligned(8))) float sAcc[TILE_WAVES][U3D_WAVE][10];
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T
                                                                    const float4* __restrict__ conic_op,
                                                                    const float* __restrict__ part,
                                                                    const uint32_t* __restrict__ part_cnt,
-                                                                   double* __restrict__ acc, int n_loss,
+                                                                   double* __restrict__ acc, uint32_t* __restrict__ touched, int n_loss,
                                                                    const float* __restrict__ loss_partial, float inv_count,
                                                                    float* __restrict__ loss_out) {
   __shared__ double s_sum[U3D_WAVE][10];
@@ -688,6 +692,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T
   const float4 co = conic_op[g];
   const double outv = moment_to_acc<double>(k, m, co.x, co.y, co.z, co.w, half_w, half_h);
   if (outv != 0.0) unsafeAtomicAdd(&acc[(size_t)k * NG + g], outv);
+  if (k == 0) touched[g] |= U3D_TOUCHED_BIT;   // this (view, Gaussian) has a non-zero row
 }
 
 // Fixed-order sum of the per-tile partials (deterministic): 1024 threads, 4 independent accumulators each.
@@ -737,11 +742,11 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
   const uint32_t nwg = (ntiles + TILE_WAVES - 1u) / TILE_WAVES;
   hipLaunchKernelGGL(render_fb_wave_kernel, dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
                      tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
-                     acc, part, loss);
+                     acc, part, b.clamped, loss);
   const int nsplit = bwd_reduce_split(T);
   hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, nsplit + 1), dim3(REDUCE_THREADS), 0, s,
                      d.P, T, U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id, b.conic_op, part,
-                     reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, (int)ntiles, loss.partial,
+                     reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, (int)ntiles, loss.partial,
                      loss.inv_count, loss_out);
 }
 
@@ -758,14 +763,14 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   if (invd)
     hipLaunchKernelGGL(render_bwd_wave_kernel<true>, dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height,
                        d.image_width, tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg,
-                       dL_dcolor, dL_dinvdepth, b.final_T, b.n_contrib, b.tile_last, acc, part, out_color, loss);
+                       dL_dcolor, dL_dinvdepth, b.final_T, b.n_contrib, b.tile_last, acc, part, out_color, b.clamped, loss);
   else
     hipLaunchKernelGGL(render_bwd_wave_kernel<false>, dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height,
                        d.image_width, tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg,
-                       dL_dcolor, dL_dinvdepth, b.final_T, b.n_contrib, b.tile_last, acc, part, out_color, loss);
+                       dL_dcolor, dL_dinvdepth, b.final_T, b.n_contrib, b.tile_last, acc, part, out_color, b.clamped, loss);
   const int nsplit = bwd_reduce_split(T);
   hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, nsplit), dim3(REDUCE_THREADS), 0, s,
                      d.P, T, invd ? U3D_NACC : U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id,
-                     b.conic_op, part, reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, 0, nullptr, 0.f,
+                     b.conic_op, part, reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, 0, nullptr, 0.f,
                      nullptr);
 }
