@@ -228,3 +228,31 @@ def test_end_to_end_standin_step_runs_and_trains():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0]
+
+
+def test_full_size_C5_geometry_properties():
+    """BASELINE config C5 geometry at full size (P = 200 000 Gaussians, 480x640, scene level, 2 of the 8 views): the largest
+    single-GPU shape -- 64 k-key radix tiles, 1200 tiles per view.  Size-independent properties: finite outputs, the fused
+    single-pass step equals the two-pass fused path and the operator chain, forward bit-repeatable, white background where
+    nothing renders, every visible Gaussian's radius positive and none for culled ones."""
+    from unipre3d_amd import fused, step
+    P, V, H, W = 200000, 2, 480, 640
+    b, bd = _batch(1, P, V, H, W, level="scene", seed=3)
+    res = []
+    for single_pass in (True, False):
+        h = bd.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+        loss, img, radii = fused.render_loss_fused(h, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt, bd.bg, bd.fov_deg,
+                                                   H, W, level="scene", offset_scale=bd.offset_scale, loss_kind="l2", single_pass=single_pass)
+        loss.backward()
+        res.append((loss.detach(), img, h.grad, radii))
+    assert all(torch.isfinite(x).all().item() for r in res for x in r[:3])
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][3], res[1][3])          # same forward kernels' arithmetic
+    assert abs(res[0][0].item() - res[1][0].item()) <= 1e-6 * abs(res[1][0].item())
+    scale = res[1][2].abs().max().item()
+    assert scale > 0 and (res[0][2] - res[1][2]).abs().max().item() <= 1e-5 * scale
+    raw = bd.raw.clone().requires_grad_(True)
+    loss_u, img_u = step.render_loss_forward(raw, bd, H, W, 0, "l2")
+    loss_u.backward()
+    assert rel_l2(res[0][1].cpu().numpy(), img_u.detach().cpu().numpy()) < 1e-5
+    assert rel_l2(res[0][2].cpu().numpy(), raw.grad.permute(0, 2, 1).cpu().numpy()) < 5 * TOL
+    assert 0.3 * P < int((res[0][3] > 0).sum().item()) / V < P                               # a real mix of visible and culled
