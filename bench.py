@@ -240,6 +240,29 @@ def main():
         except Exception as e:  # noqa: BLE001
             extras["train_step_e2e_standin"] = {"error": repr(e)[:300]}
 
+    # forward rasterizer alone (north_star: ">= 40 % of the HBM roofline in the forward rasterizer"): the operator's forward
+    # kernel (colour + inverse depth + backward state written out) on the same Gaussians, HIP events, outside the timed region
+    fwd_only = None
+    try:
+        from unipre3d_amd import head as _head
+        from unipre3d_amd.rasterizer import rasterize_gaussians_batched as _rgb
+        with torch.no_grad():
+            g_f = synthetic.gaussians_from_batch(synthetic.SyntheticBatch(**dict(batch.__dict__, raw=head_out.detach().permute(0, 2, 1))))
+            shs_f = _head.concat_sh(g_f["features_dc"], g_f["features_rest"])
+            t_f = math.tan(batch.fov_deg * math.pi / 360)
+            fwd = lambda: _rgb(g_f["xyz"], g_f["opacity"], batch.world_view, batch.full_proj, batch.camera_center, batch.bg, H, W, t_f, t_f,
+                               shs=shs_f, scales=g_f["scaling"], rotations=g_f["rotation"], sh_degree=1)
+            for _ in range(5):
+                fwd()
+            torch.cuda.synchronize()
+            _lib.profile_begin(256, ("render_fwd",))
+            for _ in range(20):
+                fwd()
+            torch.cuda.synchronize()
+            fwd_only = _lib.profile_end()["render_fwd"]
+    except Exception as e:  # noqa: BLE001
+        extras["forward_rasterizer"] = {"error": repr(e)[:300]}
+
     # statistics of the workload (outside the timed region): R = num_rendered
     from unipre3d_amd.rasterizer import _RasterizeFn  # noqa: F401
     with torch.no_grad():
@@ -286,6 +309,12 @@ def main():
             **extras,
             "final_loss": float(loss),
         }
+        if fwd_only and fwd_only[1]:
+            by = algorithmic_bytes("render_fwd", P, R_mean, tiles, H * W) * NV
+            ms = fwd_only[0] / fwd_only[1]
+            out["forward_rasterizer"] = {"kernel": "render_fwd", "avg_ms": ms, "algorithmic_GB_per_launch": by / 1e9,
+                                         "achieved_GBs": by / 1e9 / (ms / 1e3), "frac_of_8TBs": by / 1e9 / (ms / 1e3) / HBM_PEAK_GBS,
+                                         "what": "operator forward (u3d_rasterize_forward) alone: colour, inverse depth and the backward's state written to HBM"}
         if dom:
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS,
