@@ -97,7 +97,7 @@ def e2e_region(a, batch, dev, world, rank, B, V, H, W, loss_kind, timed):
     (fused activations + render + loss + backward) -> DDP all-reduce of 117.9 MB of gradients (+ SyncBN) at N > 1 ->
     NaN-check/clip -> AdamW.  The frozen SD-VAE is not part of it (synthetic decoder features)."""
     from unipre3d_amd import cameras as cams
-    from unipre3d_amd.fused import render_loss_fused
+    from unipre3d_amd.fused import backward_unit, render_loss_fused
     from unipre3d_amd.gradcheck import check_and_clip_gradients
     from unipre3d_amd.standin import PointTransformerStandIn, object_intrinsics
     g = torch.Generator().manual_seed(7 + rank)
@@ -167,7 +167,7 @@ def main():
         model.final[2].bias.zero_()
     loss_kind = "focal_l2" if level == "object" else "l2"
 
-    from unipre3d_amd.fused import render_loss_fused
+    from unipre3d_amd.fused import backward_unit, render_loss_fused
     head_out = model(feats, point_major=True).detach()
     if a.compact:                                              # secondary regime: scale = exp(N(-4, 0.5))
         head_out[..., 4:7] = -4.0 + 0.5 * head_out[..., 4:7]
@@ -182,7 +182,10 @@ def main():
             loss, _, _ = render_loss_fused(head_out, batch.center, batch.world_view, batch.full_proj, batch.camera_center, batch.gt,
                                            batch.bg, batch.fov_deg, H, W, level=level, offset_scale=batch.offset_scale,
                                            loss_kind=loss_kind, single_pass=not a.two_pass, return_images=False)
-        loss.backward()
+        if a.unfused:
+            loss.backward()
+        else:
+            backward_unit(loss)      # == loss.backward() with dL/dloss = 1 (no ones_like fill, no d_head * 1 multiply)
         return loss.detach()
 
     DOMINANT = ("render_fwd", "render_bwd", "render_fb")

@@ -256,3 +256,25 @@ def test_full_size_C5_geometry_properties():
     assert rel_l2(res[0][1].cpu().numpy(), img_u.detach().cpu().numpy()) < 1e-5
     assert rel_l2(res[0][2].cpu().numpy(), raw.grad.permute(0, 2, 1).cpu().numpy()) < 5 * TOL
     assert 0.3 * P < int((res[0][3] > 0).sum().item()) / V < P                               # a real mix of visible and culled
+
+
+def test_backward_unit_equals_loss_backward():
+    """fused.backward_unit(loss) (cached unit dL/dloss, no scaling multiply) gives bit-identical gradients to loss.backward(),
+    for the single-pass step and -- falling back to the ordinary path -- for the two-pass one; a scaled loss still scales."""
+    from unipre3d_amd import fused
+    b, bd = _batch(2, 128, 2, 64, 64, seed=9)
+    grads = []
+    for mode in ("backward", "unit", "unit_two_pass", "scaled"):
+        h = bd.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+        loss, _, _ = fused.render_loss_fused(h, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt, bd.bg, bd.fov_deg, 64, 64,
+                                             offset_scale=bd.offset_scale, loss_kind="focal_l2", single_pass=(mode != "unit_two_pass"))
+        if mode == "backward":
+            loss.backward()
+        elif mode == "scaled":
+            (2.0 * loss).backward()
+        else:
+            fused.backward_unit(loss)
+        grads.append(h.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert rel_l2(grads[2].cpu().numpy(), grads[0].cpu().numpy()) < 1e-6
+    assert rel_l2(grads[3].cpu().numpy(), 2.0 * grads[0].cpu().numpy()) < 1e-6
