@@ -190,8 +190,9 @@ int u3d_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
  *   kind: 0 preprocess_fwd, 1 depth_sort, 2 render_fwd, 3 render_bwd (+ partial reduce), 4 preprocess_bwd,
  *         5 render_fb (fused forward+backward tile kernel + partial reduce)
  * u3d_profile_begin(max_records) allocates the event ring and enables recording (U3D_ERR_INVALID_ARGUMENT
- * if already enabled); a NEGATIVE argument -((kind_mask << 20) | max_records) records only the kinds in kind_mask
- * (every recorded scope puts two event records on the stream, ~4-5 us of GPU idle each); u3d_profile_end waits for the recorded events, writes total milliseconds and launch
+ * if already enabled); a NEGATIVE argument -((stride << 26) | (kind_mask << 20) | max_records) records only the kinds in
+ * kind_mask and only every stride-th launch of a kind (stride 0 = 1; every recorded scope puts two event records on the
+ * stream, ~4-5 us of GPU idle each); u3d_profile_end waits for the recorded events, writes total milliseconds and launch
  * counts per kind into ms[U3D_PROFILE_KINDS] / count[U3D_PROFILE_KINDS], frees the events and disables.
  */
 #define U3D_PROFILE_KINDS 6

@@ -111,14 +111,15 @@ def ptr(t) -> ctypes.c_void_p:
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
-def profile_begin(max_records: int = 65536, kinds=None) -> None:
-    """kinds: iterable of PROFILE_KINDS names to record (None = all).  Each recorded scope costs ~4-5 us on the stream."""
+def profile_begin(max_records: int = 65536, kinds=None, stride: int = 1) -> None:
+    """kinds: iterable of PROFILE_KINDS names to record (None = all); stride: sample every stride-th launch of a kind (1..15).
+    Each recorded scope costs ~4-5 us on the stream."""
     arg = max_records
-    if kinds is not None:
+    if kinds is not None or stride != 1:
         mask = 0
-        for k in kinds:
+        for k in (kinds if kinds is not None else PROFILE_KINDS):
             mask |= 1 << PROFILE_KINDS.index(k)
-        arg = -((mask << 20) | min(max_records, 0xfffff))
+        arg = -((max(1, min(int(stride), 15)) << 26) | (mask << 20) | min(max_records, 0xfffff))
     check(load().u3d_profile_begin(arg), "u3d_profile_begin")
 
 

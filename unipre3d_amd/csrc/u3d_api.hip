@@ -14,6 +14,8 @@ namespace {
 struct ProfRec { hipEvent_t a, b; int kind; };
 bool g_prof_on = false;
 unsigned g_prof_mask = 0xffffffffu;   // kinds to record (bit k = kind k)
+unsigned g_prof_stride = 1;           // record every g_prof_stride-th scope of a kind
+unsigned g_prof_seen[U3D_PROFILE_KINDS] = {0};
 std::vector<ProfRec> g_prof;   // pre-created events
 size_t g_prof_used = 0;
 
@@ -21,7 +23,7 @@ struct ProfScope {
   ProfRec* r = nullptr;
   hipStream_t s;
   ProfScope(int kind, hipStream_t st) : s(st) {
-    if (g_prof_on && ((g_prof_mask >> kind) & 1u) && g_prof_used < g_prof.size()) {
+    if (g_prof_on && ((g_prof_mask >> kind) & 1u) && (g_prof_seen[kind]++ % g_prof_stride) == 0 && g_prof_used < g_prof.size()) {
       r = &g_prof[g_prof_used++];
       r->kind = kind;
       (void)hipEventRecord(r->a, s);
@@ -377,12 +379,15 @@ int u3d_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
 
 int u3d_profile_begin(int32_t max_records) {
   if (g_prof_on || max_records == 0) return U3D_ERR_INVALID_ARGUMENT;
-  // negative max_records: -(mask << 20 | records) selects a subset of kinds (each recorded scope costs two event
+  // negative max_records: -(stride << 26 | mask << 20 | records) selects a subset of kinds and samples every stride-th launch (each recorded scope costs two event
   // records on the stream, ~4-5 us of GPU idle; the timed region of bench.py records the dominant kernel only)
   g_prof_mask = 0xffffffffu;
+  g_prof_stride = 1;
+  for (auto& c : g_prof_seen) c = 0;
   if (max_records < 0) {
     const unsigned v = (unsigned)(-max_records);
-    g_prof_mask = v >> 20;
+    g_prof_mask = (v >> 20) & 0x3fu;
+    g_prof_stride = ((v >> 26) & 0xfu) ? ((v >> 26) & 0xfu) : 1u;   // sample every stride-th launch of a kind
     max_records = (int32_t)(v & 0xfffffu);
     if (max_records == 0) return U3D_ERR_INVALID_ARGUMENT;
   }
