@@ -225,6 +225,20 @@ def main():
 
     # ---- secondary regions (never `value`); a failure here must not lose the primary result ----
     extras = {}
+    if not a.unfused:
+        try:   # transparency: the same step seeded by a plain loss.backward() (autograd's ones_like fill + a d_head * 1 multiply on top)
+            def plain_step():
+                head_out.grad = None
+                l, _, _ = render_loss_fused(head_out, batch.center, batch.world_view, batch.full_proj, batch.camera_center, batch.gt, batch.bg,
+                                            batch.fov_deg, H, W, level=level, offset_scale=batch.offset_scale, loss_kind=loss_kind,
+                                            single_pass=not a.two_pass, return_images=False)
+                l.backward()
+                return l.detach()
+            el_p, _, _ = timed(plain_step, False, steps=min(a.steps, 50), warmup=5)
+            extras["hot_step_plain_loss_backward"] = {"ms_per_step": 1e3 * el_p / min(a.steps, 50),
+                                                      "what": "identical step seeded by loss.backward() instead of fused.backward_unit(loss)"}
+        except Exception as e:  # noqa: BLE001
+            extras["hot_step_plain_loss_backward"] = {"error": repr(e)[:300]}
     try:
         if a.hot_only:
             raise RuntimeError("skipped (--hot-only)")
