@@ -43,7 +43,7 @@ class _RenderLossFn(torch.autograd.Function):
         p = _lib.ptr
         rc = lib.u3d_render_loss_forward(ctypes.byref(plan.desc), ctypes.byref(hd), ctypes.byref(ld), p(bg), p(head_out), p(center),
                                          p(viewmatrix), p(projmatrix), p(campos), p(gt), p(color), p(radii), p(loss), p(geom),
-                                         p(binning), p(image), p(fused), _stream_ptr())
+                                         p(binning), p(image), p(fused), _stream_ptr(dev))
         _lib.check(rc, "u3d_render_loss_forward")
         ctx.plan, ctx.hd, ctx.ld = plan, hd, ld
         ctx.save_for_backward(head_out, center, viewmatrix, projmatrix, campos, gt, bg, color, radii, geom, binning, image, fused)
@@ -64,7 +64,7 @@ class _RenderLossFn(torch.autograd.Function):
         p = _lib.ptr
         rc = lib.u3d_render_loss_backward(ctypes.byref(ctx.plan.desc), ctypes.byref(ctx.hd), ctypes.byref(ctx.ld), p(bg), p(head_out),
                                           p(center), p(viewmatrix), p(projmatrix), p(campos), p(gt), p(radii), p(color), p(dloss),
-                                          p(geom), p(binning), p(image), p(fused), p(scratch), p(d_head), _stream_ptr())
+                                          p(geom), p(binning), p(image), p(fused), p(scratch), p(d_head), _stream_ptr(dev))
         _lib.check(rc, "u3d_render_loss_backward")
         return (d_head,) + (None,) * 17
 
@@ -98,7 +98,7 @@ class _RenderLossStepFn(torch.autograd.Function):
         p = _lib.ptr
         rc = lib.u3d_render_loss_step(ctypes.byref(plan.desc), ctypes.byref(hd), ctypes.byref(ld), p(bg), p(head_out), p(center),
                                       p(viewmatrix), p(projmatrix), p(campos), p(gt), p(color), p(radii), p(loss), p(d_head),
-                                      p(geom), p(binning), p(fused), p(scratch), _stream_ptr())
+                                      p(geom), p(binning), p(fused), p(scratch), _stream_ptr(dev))
         _lib.check(rc, "u3d_render_loss_step")
         ctx.save_for_backward(d_head)
         ctx.set_materialize_grads(False)

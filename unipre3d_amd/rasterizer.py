@@ -74,11 +74,16 @@ class _Plan:
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
-def _stream_ptr():
+def _stream_ptr(dev=None):
     """torch's CURRENT stream on the current device as a hipStream_t (the raw-handle query costs ~0.3 us, the Stream object
-    route ~10 us per call)."""
+    route ~10 us per call).  The kernels are launched on the calling thread's current HIP device, so tensors on another
+    device are refused instead of being launched against the wrong queue."""
+    cur = torch.cuda.current_device()
+    if dev is not None and dev.index is not None and dev.index != cur:
+        raise RuntimeError(f"tensors live on cuda:{dev.index} but the current device is cuda:{cur}; "
+                           f"call under torch.cuda.device({dev.index}) (one process per GPU sets it once)")
     if _raw_stream is not None:
-        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
+        return ctypes.c_void_p(_raw_stream(cur))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -107,7 +112,7 @@ class _RasterizeFn(torch.autograd.Function):
         p = _lib.ptr
         rc = lib.u3d_rasterize_forward(ctypes.byref(plan.desc), p(bg), p(means3D), p(shs), p(colors_precomp), p(opacities),
                                        p(scales), p(rotations), p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos),
-                                       p(color), p(invdepth), p(radii), p(geom), p(binning), p(image), _stream_ptr())
+                                       p(color), p(invdepth), p(radii), p(geom), p(binning), p(image), _stream_ptr(dev))
         _lib.check(rc, "u3d_rasterize_forward")
         ctx.plan = plan
         ctx.has = (shs is not None, colors_precomp is not None, scales is not None, cov3D_precomp is not None)
@@ -144,7 +149,7 @@ class _RasterizeFn(torch.autograd.Function):
                 ctypes.byref(d), p(bg), p(means3D), p(shs), p(colors_precomp), p(opacities), p(scales), p(rotations),
                 p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos), p(radii), p(grad_color), p(grad_invdepth),
                 p(geom), p(binning), p(image), p(scratch), p(g_means3D), p(g_means2D), p(g_shs), p(g_col), p(g_op),
-                p(g_scales), p(g_rot), p(g_cov), _stream_ptr())
+                p(g_scales), p(g_rot), p(g_cov), _stream_ptr(dev))
             _lib.check(rc, "u3d_rasterize_backward")
         return (g_means3D, g_means2D, g_shs, g_col if colors_precomp is not None else None, g_op, g_scales, g_rot, g_cov,
                 None, None, None, None, None, None, None, None, None, None, None, None, None)
@@ -213,7 +218,7 @@ class GaussianRasterizer(nn.Module):
             P = pos.shape[0]
             present = torch.zeros(P, dtype=torch.uint8, device=pos.device)
             rc = _lib.load().u3d_mark_visible(P, _lib.ptr(pos), _lib.ptr(_f32c(s.viewmatrix, pos.device)),
-                                              _lib.ptr(_f32c(s.projmatrix, pos.device)), _lib.ptr(present), _stream_ptr())
+                                              _lib.ptr(_f32c(s.projmatrix, pos.device)), _lib.ptr(present), _stream_ptr(pos.device))
             _lib.check(rc, "u3d_mark_visible")
         return present.bool()
 
