@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B two builds of the rasterizer library on the same box: scratch/ab.sh <libA> [configs...]
+# A/B two builds of the rasterizer library on the same box: tools/ab.sh <libA> [configs...]
 cd $GRAFT_REPO_ROOT; A=$1; shift; CFGS=${@:-C2}
 cp unipre3d_amd/lib/libunipre3d_rasterizer.so /tmp/new.so
 for rep in 1 2; do

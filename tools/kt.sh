@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel average durations (rocprofv3 kernel trace) of the bench: scratch/kt.sh <tag> [bench args]
+# per-kernel average durations (rocprofv3 kernel trace) of the bench: tools/kt.sh <tag> [bench args]
 cd /tmp && export TMPDIR=/tmp
 tag=$1; shift
 rm -rf /tmp/kt_$tag

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/pmc_sq.sh "<counters>" tag  -> gpurun_out/pmc_<tag>.txt (per-kernel averages)
+# usage: tools/pmc_sq.sh "<counters>" tag  -> gpurun_out/pmc_<tag>.txt (per-kernel averages)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_$2
 rocprofv3 --pmc $1 --kernel-trace --output-format csv -d /tmp/pmc_$2 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e > /tmp/pmc_$2.log 2>&1
