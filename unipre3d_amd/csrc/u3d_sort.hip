@@ -127,25 +127,31 @@ __device__ __forceinline__ uint32_t radix_key(int pass, int P, int idx, size_t b
   return keys_in[base + idx];
 }
 
+// Pass 0 drops the culled Gaussians (key 0xFFFFFFFF): they are neither counted nor scattered, so passes 1-3 and the
+// finalize step only see the n_vis[view] visible keys (53 % of the keys at C5); workgroups past that count leave at once.
 template <int RADIX_ITEMS>
 __global__ __launch_bounds__(U3D_BLOCK) void radix_hist_kernel(int pass, int P, int nblk, const float* __restrict__ depth,
                                                                const int32_t* __restrict__ radii,
                                                                const uint32_t* __restrict__ keys_in,
+                                                               const uint32_t* __restrict__ n_vis,
                                                                uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[256];
   const int view = blockIdx.y, blk = blockIdx.x;
   const size_t base = (size_t)view * P;
+  const int limit = pass == 0 ? P : (int)n_vis[view];
   h[threadIdx.x] = 0;
   __syncthreads();
+  if (blk * (RADIX_ITEMS * U3D_BLOCK) < limit) {
 #pragma unroll 4
-  for (int r = 0; r < RADIX_ITEMS; ++r) {
-    const int idx = blk * (RADIX_ITEMS * U3D_BLOCK) + r * U3D_BLOCK + threadIdx.x;
-    if (idx < P) {
-      const uint32_t k = radix_key(pass, P, idx, base, depth, radii, keys_in);
-      atomicAdd(&h[(k >> (8 * pass)) & 255u], 1u);
+    for (int r = 0; r < RADIX_ITEMS; ++r) {
+      const int idx = blk * (RADIX_ITEMS * U3D_BLOCK) + r * U3D_BLOCK + threadIdx.x;
+      if (idx < limit) {
+        const uint32_t k = radix_key(pass, P, idx, base, depth, radii, keys_in);
+        if (k != 0xFFFFFFFFu) atomicAdd(&h[(k >> (8 * pass)) & 255u], 1u);
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
   hist[((size_t)view * nblk + blk) * 256 + threadIdx.x] = h[threadIdx.x];   // [view][block][digit]: coalesced
 }
 
@@ -156,13 +162,16 @@ __global__ __launch_bounds__(U3D_BLOCK) void radix_scatter_kernel(int pass, int 
                                                                   const uint32_t* __restrict__ vals_in,
                                                                   uint32_t* __restrict__ keys_out,
                                                                   uint32_t* __restrict__ vals_out,
-                                                                  const uint32_t* __restrict__ hist) {
+                                                                  const uint32_t* __restrict__ hist,
+                                                                  uint32_t* __restrict__ n_vis) {
   __shared__ uint32_t digit_base[256];
   __shared__ uint32_t wave_cnt[4][256];
   const int view = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6;
   const uint32_t lane = u3d_lane_id();
   const size_t base = (size_t)view * P;
+  const int limit = pass == 0 ? P : (int)n_vis[view];
+  if (blk * (RADIX_ITEMS * U3D_BLOCK) >= limit) return;   // whole workgroup past the visible keys (uniform)
   {
     // global offset of (digit tid, this block) in digit-major / block-minor order, from the per-block counts
     // hist[view][b][digit] (every block redoes this small scan: no separate scan launch between histogram and scatter)
@@ -185,6 +194,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void radix_scatter_kernel(int pass, int 
       __syncthreads();
     }
     const uint32_t excl = digit_base[tid] - tot;
+    if (pass == 0 && blk == 0 && tid == 255) n_vis[view] = digit_base[255];   // total of the visible keys of this view
     __syncthreads();
     digit_base[tid] = excl + before;
   }
@@ -193,12 +203,13 @@ __global__ __launch_bounds__(U3D_BLOCK) void radix_scatter_kernel(int pass, int 
   __syncthreads();
   for (int r = 0; r < RADIX_ITEMS; ++r) {
     const int idx = blk * (RADIX_ITEMS * U3D_BLOCK) + r * U3D_BLOCK + tid;
-    const bool valid = idx < P;
+    bool valid = idx < limit;
     uint32_t k = 0, v = 0, digit = 0;
     if (valid) {
       k = radix_key(pass, P, idx, base, depth, radii, keys_in);
       v = pass == 0 ? (uint32_t)idx : vals_in[base + idx];
       digit = (k >> (8 * pass)) & 255u;
+      valid = k != 0xFFFFFFFFu;          // (only pass 0 meets culled entries)
     }
     // lanes of this wave holding the same digit (stable multi-split via 8 ballots)
     unsigned long long same = __ballot(valid);
@@ -228,23 +239,19 @@ __global__ __launch_bounds__(U3D_BLOCK) void radix_scatter_kernel(int pass, int 
   }
 }
 
-__global__ __launch_bounds__(U3D_BLOCK) void radix_finalize_kernel(int P, const uint32_t* __restrict__ keys,
-                                                                   const uint32_t* __restrict__ vals,
+__global__ __launch_bounds__(U3D_BLOCK) void radix_finalize_kernel(int P, const uint32_t* __restrict__ vals,
                                                                    const uint2* __restrict__ rect,
                                                                    uint32_t* __restrict__ sorted_id,
                                                                    uint2* __restrict__ sorted_rect,
-                                                                   uint32_t* __restrict__ n_vis) {
+                                                                   const uint32_t* __restrict__ n_vis) {
   const int view = blockIdx.y;
   const int i = blockIdx.x * U3D_BLOCK + threadIdx.x;
   if (i >= P) return;
   const size_t base = (size_t)view * P;
-  const uint32_t k = keys[base + i];
-  const bool vis = k != 0xFFFFFFFFu;
+  const bool vis = (uint32_t)i < n_vis[view];
   const uint32_t id = vis ? vals[base + i] : 0u;
   sorted_id[base + i] = id;
   sorted_rect[base + i] = vis ? rect[base + id] : make_uint2(0u, 0u);
-  if (i == 0 && !vis) n_vis[view] = 0;
-  if (vis && (i == P - 1 || keys[base + i + 1] == 0xFFFFFFFFu)) n_vis[view] = (uint32_t)(i + 1);
 }
 
 }  // namespace
@@ -279,16 +286,16 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
     uint32_t* kout = b.sort_keys[pass & 1];
     uint32_t* vout = b.sort_vals[pass & 1];
     if (tile == 1024) {
-      hipLaunchKernelGGL(radix_hist_kernel<4>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, b.sort_hist);
+      hipLaunchKernelGGL(radix_hist_kernel<4>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, b.n_vis, b.sort_hist);
       hipLaunchKernelGGL(radix_scatter_kernel<4>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, vin,
-                         kout, vout, b.sort_hist);
+                         kout, vout, b.sort_hist, b.n_vis);
     } else {
-      hipLaunchKernelGGL(radix_hist_kernel<16>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, b.sort_hist);
+      hipLaunchKernelGGL(radix_hist_kernel<16>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, b.n_vis, b.sort_hist);
       hipLaunchKernelGGL(radix_scatter_kernel<16>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, vin,
-                         kout, vout, b.sort_hist);
+                         kout, vout, b.sort_hist, b.n_vis);
     }
   }
   // pass 3 wrote buffer index 1
   hipLaunchKernelGGL(radix_finalize_kernel, dim3((d.P + U3D_BLOCK - 1) / U3D_BLOCK, NV), dim3(U3D_BLOCK), 0, s, d.P,
-                     b.sort_keys[1], b.sort_vals[1], b.rect, b.sorted_id, b.sorted_rect, b.n_vis);
+                     b.sort_vals[1], b.rect, b.sorted_id, b.sorted_rect, b.n_vis);
 }
