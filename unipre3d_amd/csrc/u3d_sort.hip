@@ -290,8 +290,8 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
       hipLaunchKernelGGL(radix_scatter_kernel<4>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, vin,
                          kout, vout, b.sort_hist, b.n_vis);
     } else {
-      hipLaunchKernelGGL(radix_hist_kernel<16>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, b.n_vis, b.sort_hist);
-      hipLaunchKernelGGL(radix_scatter_kernel<16>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, vin,
+      hipLaunchKernelGGL(radix_hist_kernel<8>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, b.n_vis, b.sort_hist);
+      hipLaunchKernelGGL(radix_scatter_kernel<8>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, vin,
                          kout, vout, b.sort_hist, b.n_vis);
     }
   }
