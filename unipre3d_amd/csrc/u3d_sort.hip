@@ -176,15 +176,17 @@ __global__ __launch_bounds__(U3D_BLOCK) void radix_scatter_kernel(int pass, int 
     // global offset of (digit tid, this block) in digit-major / block-minor order, from the per-block counts
     // hist[view][b][digit] (every block redoes this small scan: no separate scan launch between histogram and scatter)
     const uint32_t* col = hist + (size_t)view * nblk * 256 + tid;
-    uint32_t tot0 = 0, tot1 = 0, before = 0;
+    // (8 loads in flight: the column walk is latency-bound -- nblk is ~100-200 -- and was most of this kernel's time)
+    uint32_t tot = 0, before = 0;
     int b = 0;
-    for (; b + 1 < nblk; b += 2) {
-      const uint32_t c0 = col[(size_t)b * 256], c1 = col[(size_t)(b + 1) * 256];
-      tot0 += c0; tot1 += c1;
-      before += (b < blk ? c0 : 0u) + (b + 1 < blk ? c1 : 0u);
+    for (; b + 7 < nblk; b += 8) {
+      uint32_t c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = col[(size_t)(b + u) * 256];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { tot += c[u]; before += b + u < blk ? c[u] : 0u; }
     }
-    if (b < nblk) { const uint32_t c0 = col[(size_t)b * 256]; tot0 += c0; before += b < blk ? c0 : 0u; }
-    const uint32_t tot = tot0 + tot1;
+    for (; b < nblk; ++b) { const uint32_t c0 = col[(size_t)b * 256]; tot += c0; before += b < blk ? c0 : 0u; }
     digit_base[tid] = tot;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {   // inclusive Hillis-Steele scan of the 256 digit totals
