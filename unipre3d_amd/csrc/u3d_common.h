@@ -15,7 +15,15 @@
 #define U3D_LDS_SORT_MAX 4096  // largest per-view P sorted by one workgroup in LDS
 // keys per workgroup and radix pass (P > U3D_LDS_SORT_MAX): small tiles keep more workgroups in flight (the passes are
 // latency-bound), large tiles keep the per-block offset scan short
-static inline int u3d_radix_tile(int P) { return P <= 65536 ? 1024 : 2048; }   // measured: C4 (40 k) 75 vs 87 us, C5 (200 k) 164 vs 134 us
+// radix workgroup shapes (threads x keys per thread and pass), measured sweep on C4 (40 k keys/view) and C5 (200 k):
+// 1024 x 2 up to 64 k keys, 1024 x 4 beyond (256 x 4 / 256 x 8: 70 / 122 us; 1024 x 2 / 1024 x 4: 66 / 107 us)
+#ifndef U3D_RADIX_NT_SMALL
+#define U3D_RADIX_NT_SMALL 1024
+#define U3D_RADIX_IT_SMALL 2
+#define U3D_RADIX_NT_LARGE 1024
+#define U3D_RADIX_IT_LARGE 4
+#endif
+static inline int u3d_radix_tile(int P) { return P <= 65536 ? U3D_RADIX_NT_SMALL * U3D_RADIX_IT_SMALL : U3D_RADIX_NT_LARGE * U3D_RADIX_IT_LARGE; }
 
 // Per-call view of the carved scratch buffers (device pointers; built on the host).
 struct U3DBuffers {

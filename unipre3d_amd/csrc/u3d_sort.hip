@@ -129,22 +129,21 @@ __device__ __forceinline__ uint32_t radix_key(int pass, int P, int idx, size_t b
 
 // Pass 0 drops the culled Gaussians (key 0xFFFFFFFF): they are neither counted nor scattered, so passes 1-3 and the
 // finalize step only see the n_vis[view] visible keys (53 % of the keys at C5); workgroups past that count leave at once.
-template <int RADIX_ITEMS>
-__global__ __launch_bounds__(U3D_BLOCK) void radix_hist_kernel(int pass, int P, int nblk, const float* __restrict__ depth,
-                                                               const int32_t* __restrict__ radii,
-                                                               const uint32_t* __restrict__ keys_in,
-                                                               const uint32_t* __restrict__ n_vis,
-                                                               uint32_t* __restrict__ hist) {
+// NT threads x ITEMS keys per workgroup and pass.
+template <int NT, int ITEMS>
+__global__ __launch_bounds__(NT) void radix_hist_kernel(int pass, int P, int nblk, const float* __restrict__ depth,
+                                                        const int32_t* __restrict__ radii, const uint32_t* __restrict__ keys_in,
+                                                        const uint32_t* __restrict__ n_vis, uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[256];
-  const int view = blockIdx.y, blk = blockIdx.x;
+  const int view = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)view * P;
   const int limit = pass == 0 ? P : (int)n_vis[view];
-  h[threadIdx.x] = 0;
+  if (tid < 256) h[tid] = 0;
   __syncthreads();
-  if (blk * (RADIX_ITEMS * U3D_BLOCK) < limit) {
-#pragma unroll 4
-    for (int r = 0; r < RADIX_ITEMS; ++r) {
-      const int idx = blk * (RADIX_ITEMS * U3D_BLOCK) + r * U3D_BLOCK + threadIdx.x;
+  if (blk * (ITEMS * NT) < limit) {
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+      const int idx = blk * (ITEMS * NT) + r * NT + tid;
       if (idx < limit) {
         const uint32_t k = radix_key(pass, P, idx, base, depth, radii, keys_in);
         if (k != 0xFFFFFFFFu) atomicAdd(&h[(k >> (8 * pass)) & 255u], 1u);
@@ -152,59 +151,61 @@ __global__ __launch_bounds__(U3D_BLOCK) void radix_hist_kernel(int pass, int P, 
     }
     __syncthreads();
   }
-  hist[((size_t)view * nblk + blk) * 256 + threadIdx.x] = h[threadIdx.x];   // [view][block][digit]: coalesced
+  if (tid < 256) hist[((size_t)view * nblk + blk) * 256 + tid] = h[tid];   // [view][block][digit]: coalesced
 }
 
-template <int RADIX_ITEMS>
-__global__ __launch_bounds__(U3D_BLOCK) void radix_scatter_kernel(int pass, int P, int nblk, const float* __restrict__ depth,
-                                                                  const int32_t* __restrict__ radii,
-                                                                  const uint32_t* __restrict__ keys_in,
-                                                                  const uint32_t* __restrict__ vals_in,
-                                                                  uint32_t* __restrict__ keys_out,
-                                                                  uint32_t* __restrict__ vals_out,
-                                                                  const uint32_t* __restrict__ hist,
-                                                                  uint32_t* __restrict__ n_vis) {
+template <int NT, int ITEMS>
+__global__ __launch_bounds__(NT) void radix_scatter_kernel(int pass, int P, int nblk, const float* __restrict__ depth,
+                                                           const int32_t* __restrict__ radii, const uint32_t* __restrict__ keys_in,
+                                                           const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+                                                           uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ hist,
+                                                           uint32_t* __restrict__ n_vis) {
+  constexpr int NW = NT / 64;
   __shared__ uint32_t digit_base[256];
-  __shared__ uint32_t wave_cnt[4][256];
+  __shared__ uint32_t wave_cnt[2][NW][256];   // double-buffered per round: counts, then exclusive prefixes over the waves
+  __shared__ uint32_t wave_tot[4];
   const int view = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6;
   const uint32_t lane = u3d_lane_id();
   const size_t base = (size_t)view * P;
   const int limit = pass == 0 ? P : (int)n_vis[view];
-  if (blk * (RADIX_ITEMS * U3D_BLOCK) >= limit) return;   // whole workgroup past the visible keys (uniform)
+  if (blk * (ITEMS * NT) >= limit) return;   // whole workgroup past the visible keys (uniform)
+  for (int e = tid; e < 2 * NW * 256; e += NT) (&wave_cnt[0][0][0])[e] = 0;
   {
     // global offset of (digit tid, this block) in digit-major / block-minor order, from the per-block counts
-    // hist[view][b][digit] (every block redoes this small scan: no separate scan launch between histogram and scatter)
-    const uint32_t* col = hist + (size_t)view * nblk * 256 + tid;
-    // (8 loads in flight: the column walk is latency-bound -- nblk is ~100-200 -- and was most of this kernel's time)
-    uint32_t tot = 0, before = 0;
-    int b = 0;
-    for (; b + 7 < nblk; b += 8) {
-      uint32_t c[8];
+    // hist[view][b][digit] (every block redoes this small scan: no separate scan launch between histogram and scatter;
+    // 8 loads in flight: the column walk is latency-bound and was most of this kernel's time)
+    uint32_t tot = 0, before = 0, inc = 0;
+    if (tid < 256) {
+      const uint32_t* col = hist + (size_t)view * nblk * 256 + tid;
+      int b = 0;
+      for (; b + 7 < nblk; b += 8) {
+        uint32_t c[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) c[u] = col[(size_t)(b + u) * 256];
+        for (int u = 0; u < 8; ++u) c[u] = col[(size_t)(b + u) * 256];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { tot += c[u]; before += b + u < blk ? c[u] : 0u; }
+        for (int u = 0; u < 8; ++u) { tot += c[u]; before += b + u < blk ? c[u] : 0u; }
+      }
+      for (; b < nblk; ++b) { const uint32_t c0 = col[(size_t)b * 256]; tot += c0; before += b < blk ? c0 : 0u; }
+      inc = tot;   // inclusive scan of the 256 digit totals: shuffles inside each of the four waves, then the wave totals
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
+        if ((int)lane >= o) inc += v;
+      }
+      if (lane == 63) wave_tot[wave] = inc;
     }
-    for (; b < nblk; ++b) { const uint32_t c0 = col[(size_t)b * 256]; tot += c0; before += b < blk ? c0 : 0u; }
-    digit_base[tid] = tot;
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {   // inclusive Hillis-Steele scan of the 256 digit totals
-      const uint32_t v = tid >= o ? digit_base[tid - o] : 0u;
-      __syncthreads();
-      digit_base[tid] += v;
-      __syncthreads();
+    if (tid < 256) {
+      uint32_t off = 0;
+      for (int w = 0; w < wave; ++w) off += wave_tot[w];
+      if (pass == 0 && blk == 0 && tid == 255) n_vis[view] = off + inc;   // total of the visible keys of this view
+      digit_base[tid] = off + inc - tot + before;
     }
-    const uint32_t excl = digit_base[tid] - tot;
-    if (pass == 0 && blk == 0 && tid == 255) n_vis[view] = digit_base[255];   // total of the visible keys of this view
     __syncthreads();
-    digit_base[tid] = excl + before;
   }
-#pragma unroll
-  for (int w = 0; w < 4; ++w) wave_cnt[w][tid] = 0;
-  __syncthreads();
-  for (int r = 0; r < RADIX_ITEMS; ++r) {
-    const int idx = blk * (RADIX_ITEMS * U3D_BLOCK) + r * U3D_BLOCK + tid;
+  for (int r = 0; r < ITEMS; ++r) {
+    const int idx = blk * (ITEMS * NT) + r * NT + tid;
     bool valid = idx < limit;
     uint32_t k = 0, v = 0, digit = 0;
     if (valid) {
@@ -222,21 +223,22 @@ __global__ __launch_bounds__(U3D_BLOCK) void radix_scatter_kernel(int pass, int 
       same &= bit ? m : ~m;
     }
     const uint32_t rank = __popcll(same & ((1ull << lane) - 1ull));
-    if (valid && rank == 0) wave_cnt[wave][digit] = (uint32_t)__popcll(same);
+    uint32_t (*cnt)[256] = wave_cnt[r & 1];
+    if (valid && rank == 0) cnt[wave][digit] = (uint32_t)__popcll(same);
+    __syncthreads();
+    if (tid < 256) {   // counts -> destination of each wave's first key of this digit; digit_base moves past the round
+      uint32_t run = digit_base[tid];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = run; run += c; }
+      digit_base[tid] = run;
+    }
     __syncthreads();
     if (valid) {
-      uint32_t dst = digit_base[digit] + rank;
-      for (int w = 0; w < wave; ++w) dst += wave_cnt[w][digit];
+      const uint32_t dst = cnt[wave][digit] + rank;
       keys_out[base + dst] = k;
       vals_out[base + dst] = v;
     }
-    __syncthreads();
-    {
-      uint32_t add = 0;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) { add += wave_cnt[w][tid]; wave_cnt[w][tid] = 0; }
-      digit_base[tid] += add;
-    }
+    for (int e = tid; e < NW * 256; e += NT) (&wave_cnt[(r + 1) & 1][0][0])[e] = 0;   // the other buffer, for the next round
     __syncthreads();
   }
 }
@@ -287,15 +289,15 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
     const uint32_t* vin = pass == 0 ? nullptr : b.sort_vals[(pass + 1) & 1];
     uint32_t* kout = b.sort_keys[pass & 1];
     uint32_t* vout = b.sort_vals[pass & 1];
-    if (tile == 1024) {
-      hipLaunchKernelGGL(radix_hist_kernel<4>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, b.n_vis, b.sort_hist);
-      hipLaunchKernelGGL(radix_scatter_kernel<4>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, vin,
-                         kout, vout, b.sort_hist, b.n_vis);
-    } else {
-      hipLaunchKernelGGL(radix_hist_kernel<8>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, b.n_vis, b.sort_hist);
-      hipLaunchKernelGGL(radix_scatter_kernel<8>, dim3(nblk, NV), dim3(U3D_BLOCK), 0, s, pass, d.P, nblk, b.depth, radii, kin, vin,
-                         kout, vout, b.sort_hist, b.n_vis);
-    }
+#define LAUNCH(NT, IT)                                                                                                       \
+  do {                                                                                                                       \
+    hipLaunchKernelGGL((radix_hist_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), 0, s, pass, d.P, nblk, b.depth, radii, kin,    \
+                       b.n_vis, b.sort_hist);                                                                                \
+    hipLaunchKernelGGL((radix_scatter_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), 0, s, pass, d.P, nblk, b.depth, radii, kin, \
+                       vin, kout, vout, b.sort_hist, b.n_vis);                                                               \
+  } while (0)
+    if (d.P <= 65536) LAUNCH(U3D_RADIX_NT_SMALL, U3D_RADIX_IT_SMALL); else LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE);
+#undef LAUNCH
   }
   // pass 3 wrote buffer index 1
   hipLaunchKernelGGL(radix_finalize_kernel, dim3((d.P + U3D_BLOCK - 1) / U3D_BLOCK, NV), dim3(U3D_BLOCK), 0, s, d.P,
