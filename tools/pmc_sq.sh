@@ -2,7 +2,7 @@
 # usage: tools/pmc_sq.sh "<counters>" tag  -> gpurun_out/pmc_<tag>.txt (per-kernel averages)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_$2
-rocprofv3 --pmc $1 --kernel-trace --output-format csv -d /tmp/pmc_$2 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e > /tmp/pmc_$2.log 2>&1
+rocprofv3 --pmc $1 --kernel-trace --output-format csv -d /tmp/pmc_$2 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --hot-only $PMC_BENCH_ARGS > /tmp/pmc_$2.log 2>&1
 f=$(find /tmp/pmc_$2 -name "*counter_collection.csv" | head -1)
 python - "$f" <<'PY' > $GRAFT_REPO_ROOT/gpurun_out/pmc_$2.txt
 import csv, sys, collections

@@ -34,3 +34,6 @@ for cfgname in sys.argv[1:] or ["C2"]:
         print("mean tile_last per tile position (rows):")
         for r in m.tolist(): print(" ".join("%4.1f" % x for x in r))
         print("per-view mean: min %.1f max %.1f" % (tl.reshape(NV, -1).mean(1).min().item(), tl.reshape(NV, -1).mean(1).max().item()))
+    unsat = (lim == -1).reshape(NV, H, W)
+    tiles_unsat = unsat.reshape(NV, H // 16, 16, W // 16, 16).any(dim=4).any(dim=2)
+    print(cfgname, "unsaturated pixels %d of %d ; tiles with an unsaturated pixel %d of %d" % (int(unsat.sum()), unsat.numel(), int(tiles_unsat.sum()), tiles_unsat.numel()))

@@ -112,7 +112,12 @@ static inline size_t u3d_carve_fused(const u3d_raster_desc& d, void* base, U3DFu
   return 2 * a + (((NV * T * sizeof(float)) + 255) & ~(size_t)255) + 256;
 }
 
-#define U3D_PART_STRIDE (U3D_WAVE * 10)   // floats per tile in the partial-row buffer
+// partial-row buffer: U3D_PART_BLOCKS blocks of 64 sorted positions x 10 floats per tile (positions beyond go through f64
+// atomics); two blocks cover the ~70-95 entries a scene-level pixel needs to saturate
+#define U3D_PART_BLOCKS 2          // capacity (scratch is sized for it)
+// blocks actually used: one when the whole sorted list fits in it anyway or is short (object level), two otherwise
+static inline int u3d_part_blocks(const u3d_raster_desc& d) { return d.P <= 256 ? 1 : U3D_PART_BLOCKS; }
+#define U3D_PART_STRIDE (U3D_PART_BLOCKS * U3D_WAVE * 10)   // floats per tile
 static inline size_t u3d_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // single source of truth for carving; base pointers may be null when only sizes are wanted

@@ -77,7 +77,7 @@ __device__ __forceinline__ float min_099(float a) {   // fminf(0.99f, a) without
 //     reduction  my = dy m0, mxy = dy mx, myy = dy my;
 //   * the half-row and row levels use DPP bank masks to deposit two values into one register per instruction pair
 //     (9-10 values -> 5 -> 3 registers), and the four rows of the wave meet in three LDS float adds.
-constexpr int BWD_PART_STRIDE = U3D_PART_STRIDE;   // floats per tile: [64 positions][10], the LDS rows as they are
+constexpr int BWD_PART_STRIDE = U3D_PART_STRIDE;   // floats per tile: [U3D_PART_BLOCKS][64 positions][10], the LDS rows as they are
 // bwd_reduce_kernel: workgroups per view.  The slices of a view meet in f64 atomics (cost ~ slices), the tile chain of a
 // slice is latency-bound (cost ~ tiles per slice): ~128 tiles per slice measured best (C2: 10.4 us with 2 slices, 17 with 8).
 static inline int bwd_reduce_split(int T) { const int s = (T + 64) / 128; return s < 1 ? 1 : (s > 32 ? 32 : s); }
@@ -217,7 +217,7 @@ __device__ __forceinline__ T moment_to_acc(int k, const T* m, float a, float b, 
 // bwd_reduce_kernel.  Only sorted positions >= 64 (sparse / semi-transparent scenes) fall back to f64 global atomics,
 // whose ordering does not show at fp32 output precision (the original: one fp32 atomic per pixel and component).
 //   Tr = T_final, Rk = T_final (bg . dL/dC), lim = exclusive sorted-position limit per pixel (0: pixel takes no part).
-template <bool HAS_INVD>
+template <bool HAS_INVD, int PB /* partial-row blocks in use */>
 __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& G, int lane, uint32_t wmax, int staged,
                                               lanemask_t staged_bal, float pyf, const float (&pxf)[4],
                                               const uint32_t (&lim)[4], float (&Tr)[4], float (&Rk)[4],
@@ -351,7 +351,7 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
                      : "v"(my), "v"(mxy), "v"(m0), "v"(g_g));
       // the four 16-lane rows meet in LDS: batch 0 is indexed by sorted position (merged across tiles by
       // bwd_reduce_kernel), later batches by compaction slot
-      float* sl = &L.acc[b == 0 ? (int)pos - 1 : j][0];
+      float* sl = &L.acc[b < PB ? (int)pos - 1 - b * U3D_WAVE : j][0];
       if (row_lane) {   // (per-lane addresses on purpose: a wave-uniform one makes hipcc serialise the add over the lanes)
         atomicAdd(sl + bank, mx);
         atomicAdd(sl + 4 + bank, myy);
@@ -360,7 +360,8 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (b > 0) {
+    if (b >= PB) {
+      // sorted positions beyond the partial-row blocks (sparse / semi-transparent scenes): f64 atomics, compaction-indexed rows
       if (lane < total) {
         const size_t g = G.vbase + G.sorted_id[G.vbase + __float_as_uint(L.P2[lane].y) - 1u];
         const float4 co = G.conic_op[g];
@@ -375,19 +376,24 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
         }
         if (nz) G.touched[g] |= U3D_TOUCHED_BIT;   // (every writer ORs the same bit into an otherwise constant word)
       }
+    } else {
+      // position-indexed rows of block b: the LDS rows (raw moments) this tile can have touched, 40 B per lane, plain stores;
+      // bwd_reduce_kernel sums them over the tiles in a fixed order
+      const uint32_t cnt_b = min(wmax - (uint32_t)b * U3D_WAVE, (uint32_t)U3D_WAVE);
+      if ((uint32_t)lane < cnt_b) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          reinterpret_cast<float2*>(pt + b * (U3D_WAVE * 10))[lane * 5 + k] = reinterpret_cast<const float2*>(&L.acc[lane][0])[k];
+      }
+    }
+    if (b > 0) {
 #pragma unroll
       for (int k = 0; k < 5; ++k) reinterpret_cast<float2*>(&L.acc[lane][0])[k] = make_float2(0.f, 0.f);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
   }
-  // positions 0..63 of this tile: the LDS rows (raw moments) of the positions this tile can have touched, 40 B per lane
-  const uint32_t cnt = min(wmax, (uint32_t)U3D_WAVE);
-  if ((uint32_t)lane < cnt) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) reinterpret_cast<float2*>(pt)[lane * 5 + k] = reinterpret_cast<const float2*>(&L.acc[lane][0])[k];
-  }
-  if (lane == 0) *pcnt = cnt;
+  if (lane == 0) *pcnt = min(wmax, (uint32_t)(PB * U3D_WAVE));   // rows of this tile in the partial buffer
 }
 
 // image rows: 4 consecutive pixels per lane (one 16-byte access when W % 4 == 0)
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
 }
 
 // ---- backward (operator path, and second pass of the two-pass fused loss) ------------------------------------
-template <bool HAS_INVD>
+template <bool HAS_INVD, int PB>
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
     int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t nblocks, size_t NG,
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const float2* __restrict__ xy,
@@ -536,8 +542,8 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
     lim[k] = __float_as_uint(limf[k]);
     Rk[k] = Tr[k] * (bg[0] * dp0[k] + bg[1] * dp1[k] + bg[2] * dp2[k]);   // T_final * (bg . dL/dC)
   }
-  tile_backward<HAS_INVD>(L, G, lane, tile_last[lid], -1, 0ull, pyf, pxf, lim, Tr, Rk, dp0, dp1, dp2, dinv, 0.5f * (float)W,
-                          0.5f * (float)H, NG, acc, part + (size_t)lid * BWD_PART_STRIDE,
+  tile_backward<HAS_INVD, PB>(L, G, lane, tile_last[lid], -1, 0ull, pyf, pxf, lim, Tr, Rk, dp0, dp1, dp2, dinv, 0.5f * (float)W,
+                          0.5f * (float)H, NG, acc, part + (size_t)lid * (PB * U3D_WAVE * 10),
                           reinterpret_cast<uint32_t*>(part + (size_t)ntiles_total * BWD_PART_STRIDE) + lid);
 }
 
@@ -546,6 +552,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
 // loss term and seed dL/dcolor, and immediately walk the same LDS-resident batch back to front: final_T, the position
 // limits and the colour image never round-trip through HBM, the Gaussian batch is staged once, and one prologue
 // disappears.  dL/dloss is taken as 1 (the result is linear in it; the host scales the stored gradient).
+template <int PB>
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fb_wave_kernel(
     int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t nblocks, size_t NG,
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis,
@@ -593,8 +600,8 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fb_wave_kernel(
   for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
   if (lane == 0) loss.partial[lid] = e;
 
-  tile_backward<false>(L, G, lane, F.wlast, F.staged, F.staged_bal, pyf, pxf, F.stop_pos, F.Tr, Rk, dp0, dp1, dp2, dinv,
-                       0.5f * (float)W, 0.5f * (float)H, NG, acc, part + (size_t)lid * BWD_PART_STRIDE,
+  tile_backward<false, PB>(L, G, lane, F.wlast, F.staged, F.staged_bal, pyf, pxf, F.stop_pos, F.Tr, Rk, dp0, dp1, dp2, dinv,
+                       0.5f * (float)W, 0.5f * (float)H, NG, acc, part + (size_t)lid * (PB * U3D_WAVE * 10),
                           reinterpret_cast<uint32_t*>(part + (size_t)ntiles_total * BWD_PART_STRIDE) + lid);
 }
 
@@ -604,7 +611,112 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fb_wave_kernel(
 // positions some tile of the slice touched (cmax, usually ~20 of 64) are read at all.
 constexpr int REDUCE_THREADS = U3D_WAVE * 10;
 #define RU 32   // tiles in flight per thread
+template <int PB>
 __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T, int NK, int nsplit, size_t NG, float half_w, float half_h,
+                                                                   const uint32_t* __restrict__ sorted_id,
+                                                                   const float4* __restrict__ conic_op,
+                                                                   const float* __restrict__ part,
+                                                                   const uint32_t* __restrict__ part_cnt,
+                                                                   double* __restrict__ acc, uint32_t* __restrict__ touched, int n_loss,
+                                                                   const float* __restrict__ loss_partial, float inv_count,
+                                                                   float* __restrict__ loss_out) {
+  __shared__ double s_sum[U3D_WAVE][10];
+  __shared__ uint32_t s_cmax;
+  if ((int)blockIdx.y == nsplit) {
+    // extra row of the grid: fixed-order sum of the per-tile loss partials (replaces a separate launch)
+    if (blockIdx.x != 0) return;
+    float* sm = reinterpret_cast<float*>(&s_sum[0][0]);
+    constexpr int NT = REDUCE_THREADS;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = threadIdx.x;
+    for (; i + 3 * NT < n_loss; i += 4 * NT) {
+      a0 += loss_partial[i]; a1 += loss_partial[i + NT]; a2 += loss_partial[i + 2 * NT]; a3 += loss_partial[i + 3 * NT];
+    }
+    for (; i < n_loss; i += NT) a0 += loss_partial[i];
+    sm[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float v = 0.f;
+      for (int j = threadIdx.x; j < NT; j += 64) v += sm[j];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (threadIdx.x == 0) loss_out[0] = v * inv_count;
+    }
+    return;
+  }
+  const int view = blockIdx.x, sp = threadIdx.x / 10, k = threadIdx.x - sp * 10;
+  const int per = (T + nsplit - 1) / nsplit;
+  const int t0 = blockIdx.y * per, t1 = min(T, t0 + per);
+  const uint32_t* cnt = part_cnt + (size_t)view * T;
+  if (threadIdx.x == 0) s_cmax = 0u;
+  __syncthreads();
+  {
+    uint32_t c = 0u;
+    for (int t = t0 + (int)threadIdx.x; t < t1; t += REDUCE_THREADS) c = max(c, cnt[t]);
+    if (c != 0u) atomicMax(&s_cmax, c);
+  }
+  __syncthreads();
+  const uint32_t cmax = s_cmax;
+  if (cmax == 0u) return;
+  constexpr size_t tstride = (size_t)PB * (U3D_WAVE * 10);   // floats per tile
+#pragma unroll
+  for (int h = 0; h < PB; ++h) {   // block of 64 sorted positions (PB == 1: exactly the single-block kernel)
+    if (h > 0 && cmax <= (uint32_t)(h * U3D_WAVE)) break;
+    const uint32_t spos = (uint32_t)(h * U3D_WAVE + sp);
+    double a = 0.0;
+    if (k < NK && spos < cmax) {
+      const float* base = part + (size_t)view * T * tstride + h * (U3D_WAVE * 10) + threadIdx.x;
+      // loads are unconditional below cmax (rows a tile did not write hold stale bytes, discarded by the select) so that a
+      // whole group of tiles is in flight at once; accumulation order stays ascending in t within each of the two chains
+      double a0 = 0.0, a1 = 0.0;
+      int t = t0;
+      for (; t + RU - 1 < t1; t += RU) {
+        float v[RU];
+        uint32_t c[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          c[u] = cnt[t + u];
+          v[u] = base[(size_t)(t + u) * tstride];
+        }
+#pragma unroll
+        for (int u = 0; u < RU; u += 2) {
+          a0 += spos < c[u] ? (double)v[u] : 0.0;
+          a1 += spos < c[u + 1] ? (double)v[u + 1] : 0.0;
+        }
+      }
+      for (; t < t1; ++t) {
+        const float v0 = base[(size_t)t * tstride];
+        a0 += spos < cnt[t] ? (double)v0 : 0.0;
+      }
+      a = a0 + a1;
+    }
+    // raw moment sums of this slice -> accumulator values (linear, so slices can be converted independently)
+    if (h > 0) __syncthreads();   // the previous block's readers of s_sum are done
+    s_sum[sp][k] = a;
+    __syncthreads();
+    const bool mine = k < NK && spos < cmax;
+    if (h == PB - 1 && !mine) return;
+    if (mine) {
+      double m[U3D_NACC];
+#pragma unroll
+      for (int j = 0; j < U3D_NACC; ++j) m[j] = j < NK ? s_sum[sp][j] : 0.0;
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < U3D_NACC; ++j) any = any || m[j] != 0.0;
+      if (any) {
+        const size_t g = (size_t)view * P + sorted_id[(size_t)view * P + spos];
+        const float4 co = conic_op[g];
+        const double outv = moment_to_acc<double>(k, m, co.x, co.y, co.z, co.w, half_w, half_h);
+        if (outv != 0.0) unsafeAtomicAdd(&acc[(size_t)k * NG + g], outv);
+        if (k == 0) touched[g] |= U3D_TOUCHED_BIT;   // this (view, Gaussian) has a non-zero row
+      }
+    }
+  }
+}
+
+// Single-block form (object level: every tile's rows fit the first 64 positions): the same reduction with the block loop
+// and the per-tile stride folded away (the generic instantiation measured 2 us slower at C2).
+__global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce1_kernel(int P, int T, int NK, int nsplit, size_t NG, float half_w, float half_h,
                                                                    const uint32_t* __restrict__ sorted_id,
                                                                    const float4* __restrict__ conic_op,
                                                                    const float* __restrict__ part,
@@ -652,7 +764,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T
   if (cmax == 0u) return;
   double a = 0.0;
   if (k < NK && (uint32_t)sp < cmax) {
-    const float* base = part + (size_t)view * T * BWD_PART_STRIDE + threadIdx.x;
+    const float* base = part + (size_t)view * T * (U3D_WAVE * 10) + threadIdx.x;
     // loads are unconditional below cmax (rows a tile did not write hold stale bytes, discarded by the select) so that a
     // whole group of tiles is in flight at once; accumulation order stays ascending in t within each of the two chains
     double a0 = 0.0, a1 = 0.0;
@@ -663,7 +775,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
         c[u] = cnt[t + u];
-        v[u] = base[(size_t)(t + u) * BWD_PART_STRIDE];
+        v[u] = base[(size_t)(t + u) * (U3D_WAVE * 10)];
       }
 #pragma unroll
       for (int u = 0; u < RU; u += 2) {
@@ -672,7 +784,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T
       }
     }
     for (; t < t1; ++t) {
-      const float v0 = base[(size_t)t * BWD_PART_STRIDE];
+      const float v0 = base[(size_t)t * (U3D_WAVE * 10)];
       a0 += (uint32_t)sp < cnt[t] ? (double)v0 : 0.0;
     }
     a = a0 + a1;
@@ -694,6 +806,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T
   if (outv != 0.0) unsafeAtomicAdd(&acc[(size_t)k * NG + g], outv);
   if (k == 0) touched[g] |= U3D_TOUCHED_BIT;   // this (view, Gaussian) has a non-zero row
 }
+
 
 // Fixed-order sum of the per-tile partials (deterministic): 1024 threads, 4 independent accumulators each.
 __global__ __launch_bounds__(1024) void loss_reduce_kernel(int n, const float* __restrict__ partial, float inv_count,
@@ -740,11 +853,17 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
   const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
   if (ntiles == 0 || NG == 0) return;
   const uint32_t nwg = (ntiles + TILE_WAVES - 1u) / TILE_WAVES;
-  hipLaunchKernelGGL(render_fb_wave_kernel, dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
-                     tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
-                     acc, part, b.clamped, loss);
+  if (u3d_part_blocks(d) == 1)
+    hipLaunchKernelGGL(render_fb_wave_kernel<1>, dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
+                       tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
+                       acc, part, b.clamped, loss);
+  else
+    hipLaunchKernelGGL(render_fb_wave_kernel<U3D_PART_BLOCKS>, dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height,
+                       d.image_width, tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg,
+                       out_color, acc, part, b.clamped, loss);
   const int nsplit = bwd_reduce_split(T);
-  hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, nsplit + 1), dim3(REDUCE_THREADS), 0, s,
+  auto* reduce_k = u3d_part_blocks(d) == 1 ? bwd_reduce1_kernel : bwd_reduce_kernel<U3D_PART_BLOCKS>;
+  hipLaunchKernelGGL(reduce_k, dim3(d.n_items * d.views_per_item, nsplit + 1), dim3(REDUCE_THREADS), 0, s,
                      d.P, T, U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id, b.conic_op, part,
                      reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, (int)ntiles, loss.partial,
                      loss.inv_count, loss_out);
@@ -760,16 +879,16 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   if (ntiles == 0 || NG == 0) return;
   const uint32_t nwg = (ntiles + TILE_WAVES - 1u) / TILE_WAVES;
   const bool invd = dL_dinvdepth && loss.kind == 0;
-  if (invd)
-    hipLaunchKernelGGL(render_bwd_wave_kernel<true>, dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height,
-                       d.image_width, tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg,
-                       dL_dcolor, dL_dinvdepth, b.final_T, b.n_contrib, b.tile_last, acc, part, out_color, b.clamped, loss);
-  else
-    hipLaunchKernelGGL(render_bwd_wave_kernel<false>, dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height,
-                       d.image_width, tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg,
-                       dL_dcolor, dL_dinvdepth, b.final_T, b.n_contrib, b.tile_last, acc, part, out_color, b.clamped, loss);
+#define LAUNCH(INVD, PBV)                                                                                                   \
+  hipLaunchKernelGGL((render_bwd_wave_kernel<INVD, PBV>), dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, \
+                     d.image_width, tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg,    \
+                     dL_dcolor, dL_dinvdepth, b.final_T, b.n_contrib, b.tile_last, acc, part, out_color, b.clamped, loss)
+  if (u3d_part_blocks(d) == 1) { if (invd) LAUNCH(true, 1); else LAUNCH(false, 1); }
+  else { if (invd) LAUNCH(true, U3D_PART_BLOCKS); else LAUNCH(false, U3D_PART_BLOCKS); }
+#undef LAUNCH
   const int nsplit = bwd_reduce_split(T);
-  hipLaunchKernelGGL(bwd_reduce_kernel, dim3(d.n_items * d.views_per_item, nsplit), dim3(REDUCE_THREADS), 0, s,
+  auto* reduce_k = u3d_part_blocks(d) == 1 ? bwd_reduce1_kernel : bwd_reduce_kernel<U3D_PART_BLOCKS>;
+  hipLaunchKernelGGL(reduce_k, dim3(d.n_items * d.views_per_item, nsplit), dim3(REDUCE_THREADS), 0, s,
                      d.P, T, invd ? U3D_NACC : U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id,
                      b.conic_op, part, reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, 0, nullptr, 0.f,
                      nullptr);
