@@ -16,6 +16,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 
 import torch
@@ -223,6 +224,119 @@ def main():
     _, prof_small, _ = timed(hot_step, True, steps=10, warmup=2, kinds=("preprocess_fwd", "depth_sort", "preprocess_bwd"))
     prof = {k: (prof[k] if prof[k][1] else prof_small[k]) for k in prof}
 
+    # forward rasterizer alone (north_star: ">= 40 % of the HBM roofline in the forward rasterizer"): the operator's forward
+    # kernel (colour + inverse depth + backward state written out) on the same Gaussians, HIP events, outside the timed region
+    fwd_only, fwd_err = None, None
+    try:
+        from unipre3d_amd import head as _head
+        from unipre3d_amd.rasterizer import rasterize_gaussians_batched as _rgb
+        with torch.no_grad():
+            g_f = synthetic.gaussians_from_batch(synthetic.SyntheticBatch(**dict(batch.__dict__, raw=head_out.detach().permute(0, 2, 1))))
+            shs_f = _head.concat_sh(g_f["features_dc"], g_f["features_rest"])
+            t_f = math.tan(batch.fov_deg * math.pi / 360)
+            fwd = lambda: _rgb(g_f["xyz"], g_f["opacity"], batch.world_view, batch.full_proj, batch.camera_center, batch.bg, H, W, t_f, t_f,
+                               shs=shs_f, scales=g_f["scaling"], rotations=g_f["rotation"], sh_degree=1)
+            for _ in range(5):
+                fwd()
+            torch.cuda.synchronize()
+            _lib.profile_begin(256, ("render_fwd",))
+            for _ in range(20):
+                fwd()
+            torch.cuda.synchronize()
+            fwd_only = _lib.profile_end()["render_fwd"]
+    except Exception as e:  # noqa: BLE001
+        fwd_err = repr(e)[:300]
+
+    # statistics of the workload (outside the timed region): R = num_rendered
+    from unipre3d_amd.rasterizer import _RasterizeFn  # noqa: F401
+    with torch.no_grad():
+        g = synthetic.gaussians_from_batch(batch)
+        from unipre3d_amd import head
+        from unipre3d_amd.rasterizer import rasterize_gaussians_batched
+        t = math.tan(batch.fov_deg * math.pi / 360)
+        color, radii, _ = rasterize_gaussians_batched(g["xyz"], g["opacity"], batch.world_view, batch.full_proj, batch.camera_center,
+                                                      batch.bg, H, W, t, t, shs=head.concat_sh(g["features_dc"], g["features_rest"]),
+                                                      scales=g["scaling"], rotations=g["rotation"], sh_degree=1)
+    out = None
+    if rank == 0:
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        # R from the Gaussian rects: visible Gaussians x tiles touched is accumulated by the kernel; read it back via radii>0
+        # (exact value is in the geom scratch; recompute from an extra forward on a fresh plan for reporting)
+        from unipre3d_amd.rasterizer import _Plan
+        with torch.no_grad():   # R of the Gaussians the timed steps actually rendered (from head_out, not batch.raw)
+            g_used = synthetic.gaussians_from_batch(synthetic.SyntheticBatch(**dict(batch.__dict__, raw=head_out.detach().permute(0, 2, 1))))
+        R_mean = _read_num_rendered(g_used, batch, H, W, t)
+        NV = B * V
+        kernels = {}
+        for k, (ms, cnt) in prof.items():
+            if cnt:
+                avg_ms = ms / cnt
+                by = algorithmic_bytes(k, P, R_mean, tiles, H * W) * NV
+                kernels[k] = {"avg_ms": avg_ms, "launches": cnt, "algorithmic_GB_per_launch": by / 1e9,
+                              "achieved_GBs": by / 1e9 / (avg_ms / 1e3)}
+        hot = {k: v for k, v in kernels.items() if k in ("render_fwd", "render_bwd", "render_fb")}
+        dom = max(hot, key=lambda k: hot[k]["avg_ms"]) if hot else None
+        fwd_ms = sum(kernels[k]["avg_ms"] for k in ("preprocess_fwd", "depth_sort", "render_fwd") if k in kernels)
+        bwd_ms = sum(kernels[k]["avg_ms"] for k in ("render_bwd", "preprocess_bwd") if k in kernels)
+        fb_ms = sum(kernels[k]["avg_ms"] for k in kernels)
+        fwd_bytes = (168.0 * P + 76.0 * R_mean + 8.0 * tiles + 24.0 * H * W) * NV
+        bwd_bytes = (308.0 * P + 76.0 * R_mean + 24.0 * H * W) * NV
+        out = {
+            "metric": "rendered_views_per_sec", "value": world * NV * a.steps / elapsed, "unit": "views/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.config}: render-loss hot path (activations + render fwd + loss + render bwd), {level}-level, P={P} Gaussians/object, {H}x{W}, "
+                                   f"B={B}/GPU x V={V} views = {NV} renders/GPU/step" + (" (compact splats)" if a.compact else ""),
+                       "global_batch": B * world, "views_per_step": NV * world, "parallelism": f"dp{world}",
+                       "loss": loss_kind, "num_rendered_per_view": R_mean,
+                       "path": "unfused (torch activations/loss)" if a.unfused else "fused head-activation + render + loss (HIP)"},
+            "render_loss_step_ms": {"rasterizer_kernels_total": fb_ms, "kernels": kernels},
+            "final_loss": float(loss),
+        }
+        if dom:
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS,
+                               "traffic": pmc_traffic(dom, a.config, not (a.unfused or a.compact or a.two_pass)),
+                               "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_GB_per_launch"] * 1e9}
+            out["roofline_rasterizer_fwd_bwd"] = {"achieved": (fwd_bytes + bwd_bytes) / 1e9 / (fb_ms / 1e3), "peak": HBM_PEAK_GBS,
+                                                  "unit": "GB/s", "frac": (fwd_bytes + bwd_bytes) / 1e9 / (fb_ms / 1e3) / HBM_PEAK_GBS,
+                                                  "note": "reference-algorithm bytes fwd (168P+76R+8T+24HW) + bwd (308P+76R+24HW) per view "
+                                                          "over the sum of all rasterizer kernel times of a step"}
+        if dom and "render_fwd" in kernels:
+            out["roofline_forward_rasterizer"] = {"achieved": fwd_bytes / 1e9 / (fwd_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": fwd_bytes / 1e9 / (fwd_ms / 1e3) / HBM_PEAK_GBS,
+                                                  "note": "reference-algorithm bytes 168P+76R+8T+24HW per view over the sum of forward kernel times"}
+            out["roofline_backward_rasterizer"] = {"achieved": bwd_bytes / 1e9 / (bwd_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": bwd_bytes / 1e9 / (bwd_ms / 1e3) / HBM_PEAK_GBS}
+        if fwd_only and fwd_only[1]:
+            by = algorithmic_bytes("render_fwd", P, R_mean, tiles, H * W) * NV
+            ms = fwd_only[0] / fwd_only[1]
+            out["forward_rasterizer"] = {"kernel": "render_fwd", "avg_ms": ms, "algorithmic_GB_per_launch": by / 1e9,
+                                         "achieved_GBs": by / 1e9 / (ms / 1e3), "frac_of_8TBs": by / 1e9 / (ms / 1e3) / HBM_PEAK_GBS,
+                                         "what": "operator forward (u3d_rasterize_forward) alone: colour, inverse depth and the backward's state written to HBM"}
+        elif fwd_err:
+            out["forward_rasterizer"] = {"error": fwd_err}
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(host_batch, H, W, a.cpu_seconds)
+
+    # The contractual line is complete at this point.  The secondary regions below use RCCL (DDP) at N > 1; if one of them
+    # stalls, every rank's watchdog ends the process after the budget and rank 0 prints the line without them.
+    emitted = threading.Lock()
+
+    def emit():
+        if emitted.acquire(blocking=False) and rank == 0:
+            print(json.dumps(out), flush=True)
+
+    def on_budget():
+        if rank == 0:
+            out["secondary_regions"] = f"aborted after {extras_budget:.0f} s (primary line unaffected)"
+        emit()
+        os._exit(0)
+
+    extras_budget = float(os.environ.get("U3D_BENCH_EXTRAS_BUDGET_S", "300"))
+    watchdog = threading.Timer(extras_budget, on_budget)
+    watchdog.daemon = True
+    watchdog.start()
     # ---- secondary regions (never `value`); a failure here must not lose the primary result ----
     extras = {}
     if not a.unfused:
@@ -257,99 +371,10 @@ def main():
         except Exception as e:  # noqa: BLE001
             extras["train_step_e2e_standin"] = {"error": repr(e)[:300]}
 
-    # forward rasterizer alone (north_star: ">= 40 % of the HBM roofline in the forward rasterizer"): the operator's forward
-    # kernel (colour + inverse depth + backward state written out) on the same Gaussians, HIP events, outside the timed region
-    fwd_only = None
-    try:
-        from unipre3d_amd import head as _head
-        from unipre3d_amd.rasterizer import rasterize_gaussians_batched as _rgb
-        with torch.no_grad():
-            g_f = synthetic.gaussians_from_batch(synthetic.SyntheticBatch(**dict(batch.__dict__, raw=head_out.detach().permute(0, 2, 1))))
-            shs_f = _head.concat_sh(g_f["features_dc"], g_f["features_rest"])
-            t_f = math.tan(batch.fov_deg * math.pi / 360)
-            fwd = lambda: _rgb(g_f["xyz"], g_f["opacity"], batch.world_view, batch.full_proj, batch.camera_center, batch.bg, H, W, t_f, t_f,
-                               shs=shs_f, scales=g_f["scaling"], rotations=g_f["rotation"], sh_degree=1)
-            for _ in range(5):
-                fwd()
-            torch.cuda.synchronize()
-            _lib.profile_begin(256, ("render_fwd",))
-            for _ in range(20):
-                fwd()
-            torch.cuda.synchronize()
-            fwd_only = _lib.profile_end()["render_fwd"]
-    except Exception as e:  # noqa: BLE001
-        extras["forward_rasterizer"] = {"error": repr(e)[:300]}
-
-    # statistics of the workload (outside the timed region): R = num_rendered
-    from unipre3d_amd.rasterizer import _RasterizeFn  # noqa: F401
-    with torch.no_grad():
-        g = synthetic.gaussians_from_batch(batch)
-        from unipre3d_amd import head
-        from unipre3d_amd.rasterizer import rasterize_gaussians_batched
-        t = math.tan(batch.fov_deg * math.pi / 360)
-        color, radii, _ = rasterize_gaussians_batched(g["xyz"], g["opacity"], batch.world_view, batch.full_proj, batch.camera_center,
-                                                      batch.bg, H, W, t, t, shs=head.concat_sh(g["features_dc"], g["features_rest"]),
-                                                      scales=g["scaling"], rotations=g["rotation"], sh_degree=1)
+    watchdog.cancel()
     if rank == 0:
-        tiles = ((W + 15) // 16) * ((H + 15) // 16)
-        # R from the Gaussian rects: visible Gaussians x tiles touched is accumulated by the kernel; read it back via radii>0
-        # (exact value is in the geom scratch; recompute from an extra forward on a fresh plan for reporting)
-        from unipre3d_amd.rasterizer import _Plan
-        with torch.no_grad():   # R of the Gaussians the timed steps actually rendered (from head_out, not batch.raw)
-            g_used = synthetic.gaussians_from_batch(synthetic.SyntheticBatch(**dict(batch.__dict__, raw=head_out.detach().permute(0, 2, 1))))
-        R_mean = _read_num_rendered(g_used, batch, H, W, t)
-        NV = B * V
-        kernels = {}
-        for k, (ms, cnt) in prof.items():
-            if cnt:
-                avg_ms = ms / cnt
-                by = algorithmic_bytes(k, P, R_mean, tiles, H * W) * NV
-                kernels[k] = {"avg_ms": avg_ms, "launches": cnt, "algorithmic_GB_per_launch": by / 1e9,
-                              "achieved_GBs": by / 1e9 / (avg_ms / 1e3)}
-        hot = {k: v for k, v in kernels.items() if k in ("render_fwd", "render_bwd", "render_fb")}
-        dom = max(hot, key=lambda k: hot[k]["avg_ms"]) if hot else None
-        fwd_ms = sum(kernels[k]["avg_ms"] for k in ("preprocess_fwd", "depth_sort", "render_fwd") if k in kernels)
-        bwd_ms = sum(kernels[k]["avg_ms"] for k in ("render_bwd", "preprocess_bwd") if k in kernels)
-        fb_ms = sum(kernels[k]["avg_ms"] for k in kernels)
-        fwd_bytes = (168.0 * P + 76.0 * R_mean + 8.0 * tiles + 24.0 * H * W) * NV
-        bwd_bytes = (308.0 * P + 76.0 * R_mean + 24.0 * H * W) * NV
-        out = {
-            "metric": "rendered_views_per_sec", "value": world * NV * a.steps / elapsed, "unit": "views/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.config}: render-loss hot path (activations + render fwd + loss + render bwd), {level}-level, P={P} Gaussians/object, {H}x{W}, "
-                                   f"B={B}/GPU x V={V} views = {NV} renders/GPU/step" + (" (compact splats)" if a.compact else ""),
-                       "global_batch": B * world, "views_per_step": NV * world, "parallelism": f"dp{world}",
-                       "loss": loss_kind, "num_rendered_per_view": R_mean,
-                       "path": "unfused (torch activations/loss)" if a.unfused else "fused head-activation + render + loss (HIP)"},
-            "render_loss_step_ms": {"rasterizer_kernels_total": fb_ms, "kernels": kernels},
-            **extras,
-            "final_loss": float(loss),
-        }
-        if fwd_only and fwd_only[1]:
-            by = algorithmic_bytes("render_fwd", P, R_mean, tiles, H * W) * NV
-            ms = fwd_only[0] / fwd_only[1]
-            out["forward_rasterizer"] = {"kernel": "render_fwd", "avg_ms": ms, "algorithmic_GB_per_launch": by / 1e9,
-                                         "achieved_GBs": by / 1e9 / (ms / 1e3), "frac_of_8TBs": by / 1e9 / (ms / 1e3) / HBM_PEAK_GBS,
-                                         "what": "operator forward (u3d_rasterize_forward) alone: colour, inverse depth and the backward's state written to HBM"}
-        if dom:
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS,
-                               "traffic": pmc_traffic(dom, a.config, not (a.unfused or a.compact or a.two_pass)),
-                               "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_GB_per_launch"] * 1e9}
-            out["roofline_rasterizer_fwd_bwd"] = {"achieved": (fwd_bytes + bwd_bytes) / 1e9 / (fb_ms / 1e3), "peak": HBM_PEAK_GBS,
-                                                  "unit": "GB/s", "frac": (fwd_bytes + bwd_bytes) / 1e9 / (fb_ms / 1e3) / HBM_PEAK_GBS,
-                                                  "note": "reference-algorithm bytes fwd (168P+76R+8T+24HW) + bwd (308P+76R+24HW) per view "
-                                                          "over the sum of all rasterizer kernel times of a step"}
-        if dom and "render_fwd" in kernels:
-            out["roofline_forward_rasterizer"] = {"achieved": fwd_bytes / 1e9 / (fwd_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                  "frac": fwd_bytes / 1e9 / (fwd_ms / 1e3) / HBM_PEAK_GBS,
-                                                  "note": "reference-algorithm bytes 168P+76R+8T+24HW per view over the sum of forward kernel times"}
-            out["roofline_backward_rasterizer"] = {"achieved": bwd_bytes / 1e9 / (bwd_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                   "frac": bwd_bytes / 1e9 / (bwd_ms / 1e3) / HBM_PEAK_GBS}
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(host_batch, H, W, a.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        out.update(extras)
+    emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
