@@ -225,8 +225,10 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
                                               const float (&dinv)[4], float half_w, float half_h, size_t NG,
                                               double* __restrict__ acc, float* __restrict__ pt, uint32_t* __restrict__ pcnt) {
   constexpr int NK = HAS_INVD ? U3D_NACC : U3D_NACC - 1;
-  const bool row_lane = (lane & 3) == 0;
   const int bank = (lane >> 2) & 3;
+  const bool writer = (lane & 3) == 0 && lane < 16;   // lanes 0, 4, 8, 12: one per DPP bank
+  typedef __attribute__((address_space(3))) float lds_float;
+  const uint32_t acc_lane = (uint32_t)(uintptr_t)(lds_float*)&L.acc[0][0] + 4u * (uint32_t)bank;
   const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
   for (int b = nb - 1; b >= 0; --b) {
     lanemask_t bal = staged_bal;
@@ -351,11 +353,27 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
                      : "v"(my), "v"(mxy), "v"(m0), "v"(g_g));
       // the four 16-lane rows meet in LDS: batch 0 is indexed by sorted position (merged across tiles by
       // bwd_reduce_kernel), later batches by compaction slot
-      float* sl = &L.acc[b < PB ? (int)pos - 1 - b * U3D_WAVE : j][0];
-      if (row_lane) {   // (per-lane addresses on purpose: a wave-uniform one makes hipcc serialise the add over the lanes)
-        atomicAdd(sl + bank, mx);
-        atomicAdd(sl + 4 + bank, myy);
-        if (bank < (HAS_INVD ? 2 : 1)) atomicAdd(sl + 8 + bank, g_b);
+      const uint32_t slot = b < PB ? pos - 1u - (uint32_t)(b * U3D_WAVE) : (uint32_t)j;
+      // the four 16-lane DPP rows meet through the LDS crossbar (no LDS memory traffic, no atomics: a 16-lane ds_add_f32 occupied
+      // the CU's LDS unit for ~30 cycles, three of them per entry were 70 % of the kernel's LDS time): rows r <-> r^1 by a
+      // swizzle, halves by a bpermute; fixed summation order (r0 + r1) + (r2 + r3).  Every entry of a batch owns its row, so the
+      // totals are plain stores.
+      {
+        const int xaddr = (lane ^ 32) << 2;
+        float t0 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(mx), 0x401f));    // lane ^ 16
+        float t1 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(myy), 0x401f));
+        float t2 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(g_b), 0x401f));
+        mx += t0; myy += t1; g_b += t2;
+        t0 = __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(mx)));
+        t1 = __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(myy)));
+        t2 = __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(g_b)));
+        mx += t0; myy += t1; g_b += t2;
+      }
+      if (writer) {   // 32-bit LDS addresses (generic-pointer indexing costs a 64-bit multiply-add and a second address register)
+        lds_float* sl = reinterpret_cast<lds_float*>(acc_lane + __umul24(slot, 40u));
+        sl[0] = mx;
+        sl[4] = myy;
+        if (bank < (HAS_INVD ? 2 : 1)) sl[8] = g_b;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
