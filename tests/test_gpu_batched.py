@@ -127,11 +127,15 @@ def test_full_size_C2_properties(oracle_mod):
 @pytest.mark.parametrize("level,loss_kind,P,V,H,W", [("object", "focal_l2", 128, 4, 128, 128), ("object", "l2", 300, 2, 64, 96),
                                                       ("scene", "l2", 500, 3, 120, 160), ("object", "l1", 64, 2, 48, 48)])
 @pytest.mark.parametrize("single_pass", [False, True])
-def test_fused_render_loss_equals_unfused_path(level, loss_kind, P, V, H, W, single_pass):
+@pytest.mark.parametrize("opaque", [False, True])
+def test_fused_render_loss_equals_unfused_path(level, loss_kind, P, V, H, W, single_pass, opaque):
     """N2+N3: head-activation + render + loss in the HIP library == torch activations + batched operator + torch loss,
-    for the loss value and for the gradient w.r.t. the raw head output."""
+    for the loss value and for the gradient w.r.t. the raw head output.  `opaque`: every 9th Gaussian gets opacity
+    sigmoid(6) = 0.9975, so tiles leave the clamp-free loop variant (tile_stage in u3d_render.hip) and the 0.99 clamp is live."""
     from unipre3d_amd import fused, step
     b, bd = _batch(2, P, V, H, W, level=level, seed=11)
+    if opaque:
+        bd.raw[:, 3, ::9] = 6.0
     head_out = bd.raw.permute(0, 2, 1).contiguous().requires_grad_(True)      # (B,P,23): what `final` emits
     loss_f, img_f, radii_f = fused.render_loss_fused(head_out, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt,
                                                      bd.bg, bd.fov_deg, H, W, level=level, offset_scale=bd.offset_scale,

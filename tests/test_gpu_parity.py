@@ -180,3 +180,73 @@ def test_truly_compact_splats_operator_level(oracle_mod, P, H, W, level):
     go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
     for k in DIFF_KEYS + ("means2D",):
         assert near(gr[k].reshape(go[k].shape), go[k], go64[k]), k
+
+
+def _tile_flags(color, H, W):
+    """tile_last words of the forward that produced `color` (image scratch saved for backward): (last position, ran-plain flag)."""
+    fn = color.grad_fn
+    while not type(fn).__name__.startswith("_Rasterize"):   # through the per-view select / reshape nodes
+        fn = fn.next_functions[0][0]
+    image = fn.saved_tensors[-1]
+    al = lambda n: ((n + 255) // 256) * 256
+    T = ((H + 15) // 16) * ((W + 15) // 16)
+    tl = image[al(H * W * 4) * 2:][: T * 4].view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
+    return tl & 0x7fffffff, (tl >> 31).astype(bool)
+
+
+@pytest.mark.parametrize("P,fade,every", [(200, 1.0, 7), (700, 0.05, 50), (700, 0.05, 333)])
+def test_loop_variants_high_opacity(oracle_mod, P, fade, every):
+    """The tile kernels run a loop variant without the 0.99 clamp / pw test while every staged Gaussian has opacity <= 0.98
+    and a safely definite conic, and restart the tile with the full variant at the first batch that does not qualify.
+    Opacities in (0.98, 1] sprinkled over the sorted list (first batch, and deep batches when the rest of the scene is faint)
+    must give the oracle's image and gradients -- including the pass-through gradient of the clamp -- through both variants."""
+    H = W = 64
+    sc = scene(P, H, W, seed=31)
+    sc["opacities"] = sc["opacities"] * fade
+    sc["opacities"][::every] = torch.linspace(0.981, 1.0, len(sc["opacities"][::every]))[:, None]
+    dcol, dinv = cotangents(H, W)
+    color, invd, radii, g = _run_gpu(sc, dcol, dinv)
+    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
+    go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
+    assert np.array_equal(radii, r.radii) and near(color, r.color, r64.color) and near(invd, r.invdepth, r64.invdepth)
+    for k in DIFF_KEYS + ("means2D",):
+        assert near(g[k].reshape(go[k].shape), go[k], go64[k]), k
+
+
+def test_loop_variant_selection(oracle_mod):
+    """Which tiles may take the plain variant: all of them for an ordinary scene, none of those a Gaussian with opacity > 0.98 or
+    a nearly singular conic (a 20 m x 1 mm needle: b^2 within 1e-5 of a c) reaches before they saturate."""
+    from unipre3d_amd.rasterizer import rasterize_gaussians
+    dev = torch.device("cuda:0")
+    H = W = 64
+
+    def flags(sc):
+        t = {k: (v.to(dev).requires_grad_(k in DIFF_KEYS) if torch.is_tensor(v) else v) for k, v in sc.items()}
+        color, radii, _ = rasterize_gaussians(t["means3D"], torch.zeros_like(t["means3D"]), t["shs"], None, t["opacities"], t["scales"],
+                                              t["rotations"], None, _settings(sc, t))
+        torch.cuda.synchronize()
+        return _tile_flags(color, H, W), radii.cpu().numpy()
+
+    sc = scene(100, H, W, seed=5)
+    sc["opacities"].clamp_(max=0.9)
+    (last, plain), radii = flags(sc)
+    assert plain.all() and (last > 0).all()
+    # one opaque Gaussian, nearest to the camera (first in every tile's list)
+    r = oracle_mod.forward(dtype=np.float32, **to_numpy(sc))
+    depth = (np.c_[to_numpy(sc)["means3D"], np.ones(100)] @ to_numpy(sc)["viewmatrix"])[:, 2]
+    first = int(np.argmin(np.where(r.radii > 0, depth, np.inf)))
+    sc2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in sc.items()}
+    sc2["opacities"][first] = 0.985
+    sc2["scales"][first] = 3.0          # large enough to be in every tile's list
+    (last2, plain2), _ = flags(sc2)
+    assert not plain2.any()
+    # a needle at the same place with ordinary opacity: 20 m x 1 mm, its axis along the image diagonal (camera-space (1,1,0)/sqrt 2)
+    sc3 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in sc.items()}
+    V3 = sc["viewmatrix"][:3, :3].double()                      # row-vector convention: p_view = p_world @ V3
+    w = (torch.tensor([1.0, 1.0, 0.0], dtype=torch.float64) / 2 ** 0.5) @ V3.T
+    ex = torch.tensor([1.0, 0.0, 0.0], dtype=torch.float64)
+    q = torch.cat([(1.0 + ex @ w)[None], torch.linalg.cross(ex, w)])
+    sc3["rotations"][first] = (q / q.norm()).float()
+    sc3["scales"][first] = torch.tensor([20.0, 1e-3, 1e-3])
+    (last3, plain3), _ = flags(sc3)
+    assert not plain3.all()

@@ -44,7 +44,7 @@ _lib.load().u3d_rasterize_forward(ctypes.byref(plan.desc), p(batch.bg), p(c(g["x
     p(color), p(None), p(radii), p(geom), p(binning), p(image), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 torch.cuda.synchronize()
 npx = NV * H * W; al = lambda n: ((n + 255) // 256) * 256; T = (H // 16) * (W // 16)
-tl = image[al(npx * 4) * 2: al(npx * 4) * 2 + NV * T * 4].view(torch.int32).float().reshape(B, V, T)
+tl = image[al(npx * 4) * 2: al(npx * 4) * 2 + NV * T * 4].view(torch.int32).bitwise_and(0x7fffffff).float().reshape(B, V, T)
 cost = tl.sum((1, 2))
 print("per-item cost min %.0f max %.0f mean %.0f ; per-view min %.1f max %.1f" % (cost.min(), cost.max(), cost.mean(), tl.mean(2).min(), tl.mean(2).max()))
 ident = torch.arange(B, device=dev)

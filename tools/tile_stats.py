@@ -25,7 +25,7 @@ for cfgname in sys.argv[1:] or ["C2"]:
     al = lambda n: ((n + 255) // 256) * 256
     T = ((H + 15) // 16) * ((W + 15) // 16)
     off = al(npx * 4) * 2
-    tl = image[off: off + NV * T * 4].view(torch.int32).float()
+    tl = image[off: off + NV * T * 4].view(torch.int32).bitwise_and(0x7fffffff).float()   # bit 31: the tile ran the plain loop variant
     lim = image[al(npx * 4):][: npx * 4].view(torch.int32)
     sat = (lim != -1).float().mean().item()
     print(cfgname, "tile_last mean %.1f  median %.1f  frac>64 %.3f  max %d ; pixels saturated %.3f ; visible/view %.1f" % (tl.mean().item(), tl.median().item(), (tl > 64).float().mean().item(), int(tl.max().item()), sat, (radii > 0).float().sum(1).mean().item()))

@@ -11,6 +11,7 @@
 // set in `clamped` by the gradient reduction for every (view, Gaussian) that received a non-zero row: preprocess_bwd reads the
 // 80 B of accumulators only for those (a pixel saturates after a few dozen entries, so most visible Gaussians get none)
 #define U3D_TOUCHED_BIT 0x80000000u
+#define U3D_TILE_PLAIN_BIT 0x80000000u   /* tile_last: the forward ran the loop variant without clamp / pw test */
 #define U3D_NACC 10         // mean2D.xy, conic(a, b/2, c), opacity, rgb, invdepth
 #define U3D_LDS_SORT_MAX 4096  // largest per-view P sorted by one workgroup in LDS
 // keys per workgroup and radix pass (P > U3D_LDS_SORT_MAX): small tiles keep more workgroups in flight (the passes are

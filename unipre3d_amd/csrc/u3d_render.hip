@@ -96,11 +96,20 @@ struct TileGeom {
   uint32_t* touched;   // the `clamped` words (U3D_TOUCHED_BIT), backward only
 };
 
-// stage sorted entries [b*64, b*64+64) limited to `limit`; returns the hit ballot (compaction keeps the order)
+// stage sorted entries [b*64, b*64+64) limited to `limit`; returns the hit ballot (compaction keeps the order).
+// `plain` (wave-uniform) is set when, for EVERY staged entry, two of the per-pixel tests of the blend are provably no-ops, so the
+// batch may run the loop variants without them (8 fewer 4-cycle instructions per Gaussian and pass):
+//   * opacity <= 0.98: alpha = opacity * exp2(pw) <= 0.99 whenever pw <= 0, i.e. min(0.99, .) changes nothing;
+//   * the staged quadratic form is negative semi-definite with margin, a', c' <= 0 and b'^2 <= 4 a' c' (1 - 1e-5): the computed
+//     pw = fma(fma(a', dx, b' dy), dx, (c' dy) dy) differs from the exact form by at most 4 * 2^-24 (|a'| dx^2 + |c'| dy^2),
+//     while the exact form is <= -(1e-5 / 2) (|a'| dx^2 + |c'| dy^2): the `pw > 0 -> skip` test can never fire (the pixel
+//     centre is finite; NaN alphas still fail the alpha >= 1/255 test).
+// Any entry outside these bounds (opacity above 0.98, a nearly singular or non-finite conic) sends the whole batch through the
+// loops that carry both tests, so results are identical either way.
 template <bool DEPTH>
-__device__ __forceinline__ lanemask_t tile_stage(const TileLds& L, const TileGeom& G, int lane, int b, uint32_t limit) {
+__device__ __forceinline__ lanemask_t tile_stage(const TileLds& L, const TileGeom& G, int lane, int b, uint32_t limit, bool& plain) {
   const uint32_t s = (uint32_t)b * U3D_WAVE + (uint32_t)lane;
-  bool hit = false;
+  bool hit = false, ok = true;
   if (s < limit) hit = rect_hits(G.sorted_rect[G.vbase + s], G.tx, G.ty);
   const lanemask_t bal = __ballot(hit);
   if (hit) {
@@ -109,11 +118,14 @@ __device__ __forceinline__ lanemask_t tile_stage(const TileLds& L, const TileGeo
     const float2 m = G.xy[g];
     const float4 co = G.conic_op[g];
     const float4 cd = G.rgbd[g];
-    L.P0[o] = make_float4(m.x, m.y, (-0.5f * LOG2E) * co.x, -LOG2E * co.y);
-    L.P1[o] = make_float4((-0.5f * LOG2E) * co.z, co.w, cd.x, cd.y);
+    const float a1 = (-0.5f * LOG2E) * co.x, b1 = -LOG2E * co.y, c1 = (-0.5f * LOG2E) * co.z;
+    L.P0[o] = make_float4(m.x, m.y, a1, b1);
+    L.P1[o] = make_float4(c1, co.w, cd.x, cd.y);
     L.P2[o] = make_float2(cd.z, __uint_as_float(s + 1u));
     if (DEPTH) L.D[o] = 1.0f / cd.w;
+    ok = a1 <= 0.f && c1 <= 0.f && b1 * b1 <= (4.f * (1.f - 1e-5f)) * (a1 * c1) && co.w <= 0.98f && fabsf(m.x) < 1e30f && fabsf(m.y) < 1e30f;
   }
+  plain = __ballot(!ok) == 0ull;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   return bal;
@@ -129,8 +141,10 @@ struct TileFwd {
 
 // front-to-back blend of the view's sorted list over this tile.  The wave leaves as soon as all
 // of its 256 pixels are saturated.
-template <bool DEPTH>
-__device__ __forceinline__ void tile_forward(const TileLds& L, const TileGeom& G, int lane, uint32_t nv, float pyf,
+// PLAIN: the loop variant without the clamp and the pw test (see tile_stage); it gives up (returns false, F unusable) at the first
+// batch that does not qualify, and the caller runs the tile again with PLAIN = false.
+template <bool DEPTH, bool PLAIN>
+__device__ __forceinline__ bool tile_forward(const TileLds& L, const TileGeom& G, int lane, uint32_t nv, float pyf,
                                              const float (&pxf)[4], const bool (&inside)[4], TileFwd& F) {
   float amin[4];
 #pragma unroll
@@ -144,7 +158,9 @@ __device__ __forceinline__ void tile_forward(const TileLds& L, const TileGeom& G
   bool wave_done = false;
   const int nbf = (int)((nv + U3D_WAVE - 1) / U3D_WAVE);
   for (int b = 0; b < nbf && !wave_done; ++b) {
-    const lanemask_t bal = tile_stage<DEPTH>(L, G, lane, b, nv);
+    bool plain;
+    const lanemask_t bal = tile_stage<DEPTH>(L, G, lane, b, nv, plain);
+    if (PLAIN && !plain) return false;
     F.staged = b; F.staged_bal = bal;
     const int total = __popcll(bal);
     for (int j = 0; j < total; ++j) {
@@ -159,8 +175,10 @@ __device__ __forceinline__ void tile_forward(const TileLds& L, const TileGeom& G
       for (int k = 0; k < 4; ++k) {   // one basic block: the four pixels' dependency chains interleave
         const float dx = A.x - pxf[k];
         const float pw = fmaf(fmaf(A.z, dx, bdy), dx, cdy2);
-        const float alpha = min_099(Q.y * __builtin_amdgcn_exp2f(pw));
-        const lanemask_t m_ok = __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE) & __builtin_amdgcn_fcmpf(alpha, amin[k], U3D_FCMP_OGE);
+        const float araw = Q.y * __builtin_amdgcn_exp2f(pw);
+        const float alpha = PLAIN ? araw : min_099(araw);
+        const lanemask_t m_ok = PLAIN ? __builtin_amdgcn_fcmpf(alpha, amin[k], U3D_FCMP_OGE)
+                                      : __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE) & __builtin_amdgcn_fcmpf(alpha, amin[k], U3D_FCMP_OGE);
         const float w = alpha * F.Tr[k];
         const float test_T = F.Tr[k] - w;          // T (1 - alpha)
         const lanemask_t m_lt = __builtin_amdgcn_fcmpf(test_T, T_STOP, U3D_FCMP_OLT);
@@ -190,6 +208,7 @@ __device__ __forceinline__ void tile_forward(const TileLds& L, const TileGeom& G
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  return true;
 }
 
 // Per-Gaussian gradient rows travel as RAW moments (mx, my, mxx, mxy, myy, m0, r, g, b, d); they are linear in the pixels, so
@@ -217,7 +236,7 @@ __device__ __forceinline__ T moment_to_acc(int k, const T* m, float a, float b, 
 // bwd_reduce_kernel.  Only sorted positions >= 64 (sparse / semi-transparent scenes) fall back to f64 global atomics,
 // whose ordering does not show at fp32 output precision (the original: one fp32 atomic per pixel and component).
 //   Tr = T_final, Rk = T_final (bg . dL/dC), lim = exclusive sorted-position limit per pixel (0: pixel takes no part).
-template <bool HAS_INVD, int PB /* partial-row blocks in use */>
+template <bool HAS_INVD, int PB /* partial-row blocks in use */, bool PLAIN /* every batch of the tile qualified in the forward pass */>
 __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& G, int lane, uint32_t wmax, int staged,
                                               lanemask_t staged_bal, float pyf, const float (&pxf)[4],
                                               const uint32_t (&lim)[4], float (&Tr)[4], float (&Rk)[4],
@@ -232,7 +251,7 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
   const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
   for (int b = nb - 1; b >= 0; --b) {
     lanemask_t bal = staged_bal;
-    if (b != staged) { bal = tile_stage<HAS_INVD>(L, G, lane, b, wmax); staged = b; staged_bal = bal; }
+    if (b != staged) { bool plain; bal = tile_stage<HAS_INVD>(L, G, lane, b, wmax, plain); staged = b; staged_bal = bal; }
     // entries of this batch with pos <= wmax (the compaction keeps positions ascending)
     const uint32_t lm = wmax - (uint32_t)b * U3D_WAVE;
     const int total = lm >= U3D_WAVE ? __popcll(bal) : __popcll(bal & ((1ull << lm) - 1ull));
@@ -251,7 +270,7 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
         dx[k] = A.x - pxf[k];
         const float pw = fmaf(fmaf(A.z, dx[k], bdy), dx[k], cdy2);
         const float araw = Q.y * __builtin_amdgcn_exp2f(pw);   // opacity * G (alpha before the 0.99 clamp)
-        const lanemask_t m = __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE) & __builtin_amdgcn_fcmpf(araw, ALPHA_MIN, U3D_FCMP_OGE) &
+        const lanemask_t m = (PLAIN ? ~0ull : __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE)) & __builtin_amdgcn_fcmpf(araw, ALPHA_MIN, U3D_FCMP_OGE) &
                              __builtin_amdgcn_uicmp(pos, lim[k], U3D_ICMP_ULT);
         any |= m;
         ae[k] = mask_sel0(m, araw);
@@ -260,7 +279,7 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
       float m0, mx, mxx, g_r, g_g, g_b, g_d = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float alpha = min_099(ae[k]);
+        const float alpha = PLAIN ? ae[k] : min_099(ae[k]);
         const float om = 1.f - alpha;
         const float rc = __builtin_amdgcn_rcpf(om);
         const float Tn = Tr[k] * rc;            // T in front of this Gaussian
@@ -446,6 +465,11 @@ __device__ __forceinline__ void loss_seed(const U3DLoss& loss, const float* __re
   }
 }
 
+// The tile kernels carry two loop variants each (PLAIN and not); left alone, the register allocator takes 75-77 VGPRs for the pair
+// (6 waves per SIMD).  For the single-pass kernel, pinning 8 waves per SIMD (64 VGPRs) spills a handful of values around the rarely
+// taken variant and measured 3 % faster than the unpinned build, 4.5 % faster than the single-variant kernel; the two-pass kernels
+// measured slower pinned (forward 97 against 87 us at C2) and are left to the allocator.
+#define U3D_FULL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(8, 8)))
 #define U3D_TILE_PROLOGUE(NWAVES)                                                                       \
   const int tid = threadIdx.x, wave = (NWAVES) == 1 ? 0 : tid >> 6, lane = tid & 63; /* 1: all ids scalar */ \
   const uint32_t lid = (NWAVES) == 1 ? u3d_xcd_remap_view(blockIdx.x, (uint32_t)T)                     \
@@ -483,7 +507,9 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
   U3D_TILE_PROLOGUE(TILE_WAVES);
   const TileLds L{sP0[wave], sP1[wave], sP2[wave], sD[wave], nullptr};
   TileFwd F;
-  tile_forward<true>(L, G, lane, n_vis[view], pyf, pxf, inside, F);
+  const uint32_t nv = n_vis[view];
+  const bool plain = tile_forward<true, true>(L, G, lane, nv, pyf, pxf, inside, F);
+  if (!plain) tile_forward<true, false>(L, G, lane, nv, pyf, pxf, inside, F);
 
   float o0[4], o1[4], o2[4], lim[4];
 #pragma unroll
@@ -497,7 +523,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
   store4(out_color + cid0 + npix, vec, inside, o1);
   store4(out_color + cid0 + 2 * npix, vec, inside, o2);
   if (out_invdepth) store4(out_invdepth + pid0, vec, inside, F.Dv);
-  if (lane == 0) tile_last[lid] = F.wlast;
+  if (lane == 0) tile_last[lid] = F.wlast | (plain ? U3D_TILE_PLAIN_BIT : 0u);   // the backward kernel takes the same loop variant
   if (loss.kind != 0) {
     float g0[4], g1[4], g2[4], e = 0.f;
     load4(loss.gt + cid0, vec, inside, g0);
@@ -560,7 +586,13 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
     lim[k] = __float_as_uint(limf[k]);
     Rk[k] = Tr[k] * (bg[0] * dp0[k] + bg[1] * dp1[k] + bg[2] * dp2[k]);   // T_final * (bg . dL/dC)
   }
-  tile_backward<HAS_INVD, PB>(L, G, lane, tile_last[lid], -1, 0ull, pyf, pxf, lim, Tr, Rk, dp0, dp1, dp2, dinv, 0.5f * (float)W,
+  const uint32_t tl = tile_last[lid];
+  if (tl & U3D_TILE_PLAIN_BIT)
+    tile_backward<HAS_INVD, PB, true>(L, G, lane, tl & ~U3D_TILE_PLAIN_BIT, -1, 0ull, pyf, pxf, lim, Tr, Rk, dp0, dp1, dp2, dinv, 0.5f * (float)W,
+                          0.5f * (float)H, NG, acc, part + (size_t)lid * (PB * U3D_WAVE * 10),
+                          reinterpret_cast<uint32_t*>(part + (size_t)ntiles_total * BWD_PART_STRIDE) + lid);
+  else
+    tile_backward<HAS_INVD, PB, false>(L, G, lane, tl, -1, 0ull, pyf, pxf, lim, Tr, Rk, dp0, dp1, dp2, dinv, 0.5f * (float)W,
                           0.5f * (float)H, NG, acc, part + (size_t)lid * (PB * U3D_WAVE * 10),
                           reinterpret_cast<uint32_t*>(part + (size_t)ntiles_total * BWD_PART_STRIDE) + lid);
 }
@@ -571,7 +603,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
 // limits and the colour image never round-trip through HBM, the Gaussian batch is staged once, and one prologue
 // disappears.  dL/dloss is taken as 1 (the result is linear in it; the host scales the stored gradient).
 template <int PB>
-__global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fb_wave_kernel(
+__global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void render_fb_wave_kernel(
     int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t nblocks, size_t NG,
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis,
     const float2* __restrict__ xy, const float4* __restrict__ conic_op, const float4* __restrict__ rgbd,
@@ -585,7 +617,9 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fb_wave_kernel(
 #pragma unroll
   for (int k = 0; k < 5; ++k) reinterpret_cast<float2*>(&sAcc[wave][lane][0])[k] = make_float2(0.f, 0.f);
   TileFwd F;
-  tile_forward<false>(L, G, lane, n_vis[view], pyf, pxf, inside, F);
+  const uint32_t nv = n_vis[view];
+  const bool plain = tile_forward<false, true>(L, G, lane, nv, pyf, pxf, inside, F);
+  if (!plain) tile_forward<false, false>(L, G, lane, nv, pyf, pxf, inside, F);
 
   // loss term, dL/dcolor seed
   float dp0[4], dp1[4], dp2[4], dinv[4], Rk[4], o0[4], o1[4], o2[4], g0[4], g1[4], g2[4];
@@ -618,7 +652,12 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fb_wave_kernel(
   for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
   if (lane == 0) loss.partial[lid] = e;
 
-  tile_backward<false, PB>(L, G, lane, F.wlast, F.staged, F.staged_bal, pyf, pxf, F.stop_pos, F.Tr, Rk, dp0, dp1, dp2, dinv,
+  if (plain)
+    tile_backward<false, PB, true>(L, G, lane, F.wlast, F.staged, F.staged_bal, pyf, pxf, F.stop_pos, F.Tr, Rk, dp0, dp1, dp2, dinv,
+                       0.5f * (float)W, 0.5f * (float)H, NG, acc, part + (size_t)lid * (PB * U3D_WAVE * 10),
+                          reinterpret_cast<uint32_t*>(part + (size_t)ntiles_total * BWD_PART_STRIDE) + lid);
+  else
+    tile_backward<false, PB, false>(L, G, lane, F.wlast, F.staged, F.staged_bal, pyf, pxf, F.stop_pos, F.Tr, Rk, dp0, dp1, dp2, dinv,
                        0.5f * (float)W, 0.5f * (float)H, NG, acc, part + (size_t)lid * (PB * U3D_WAVE * 10),
                           reinterpret_cast<uint32_t*>(part + (size_t)ntiles_total * BWD_PART_STRIDE) + lid);
 }
