@@ -216,12 +216,15 @@ __device__ __forceinline__ uint32_t u3d_xcd_remap(uint32_t bid, uint32_t nblocks
 // level) while neighbouring tiles -- which share image cache lines and the view's Gaussian state -- still meet in one L2.
 // Bijective on [0, nviews*T) for any T: block b sits on XCD b % 8; within view v (blocks [vT, vT+T)) the blocks of residue
 // class x are numbered in order and mapped to the x-th chunk of the view's tile range.
-__device__ __forceinline__ uint32_t u3d_xcd_remap_view(uint32_t bid, uint32_t T) {
-  const uint32_t view = bid / T, j = bid - view * T;
+__device__ __forceinline__ uint32_t u3d_xcd_chunk_in_view(uint32_t j, uint32_t view, uint32_t T) {   // tile (within the view) of block j
   const uint32_t r = (view * T) & 7u, m = r + j, x = m & 7u;
   auto below = [](uint32_t n, uint32_t c) { return (n >> 3) * c + min(n & 7u, c); };   // #{i < n : i % 8 < c}
   const uint32_t k = ((m + 7u - x) >> 3) - ((r + 7u - x) >> 3);                         // rank of this block in its class
-  return view * T + (below(r + T, x) - below(r, x)) + k;
+  return (below(r + T, x) - below(r, x)) + k;
+}
+__device__ __forceinline__ uint32_t u3d_xcd_remap_view(uint32_t bid, uint32_t T) {   // linear form: bid = view * T + j
+  const uint32_t view = bid / T;
+  return view * T + u3d_xcd_chunk_in_view(bid - view * T, view, T);
 }
 
 __device__ __forceinline__ uint32_t u3d_lane_id() {

@@ -23,17 +23,39 @@ __device__ __forceinline__ bool rect_hits(const uint2 r, int tx, int ty) {
   return tx >= x0 && tx < x1 && ty >= y0 && ty < y1;
 }
 
-// per-pixel loss term and its weight (utils/loss_utils.py:20-45).  torch.isclose(gt, bg, atol=1e-6) uses rtol=1e-5.
-__device__ __forceinline__ float focal_weight(const U3DLoss& L, const float* __restrict__ bg, float g0, float g1, float g2) {
-  if (L.kind != 2) return 1.f;
-  const bool is_bg = fabsf(g0 - bg[0]) <= 1e-6f + 1e-5f * fabsf(bg[0]) && fabsf(g1 - bg[1]) <= 1e-6f + 1e-5f * fabsf(bg[1]) &&
-                     fabsf(g2 - bg[2]) <= 1e-6f + 1e-5f * fabsf(bg[2]);
-  return is_bg ? L.w_bg : L.w_non;
+// Render loss of one pixel (utils/loss_utils.py:17-45), branch-free in the lane: a pixel outside the image gets weight 0.
+// torch.isclose(gt, bg, atol=1e-6) uses rtol=1e-5; the per-channel bounds and the background are wave-uniform.
+struct LossCtx {
+  int kind;
+  float w_bg, w_non, b0, b1, b2, t0, t1, t2;
+};
+__device__ __forceinline__ LossCtx loss_ctx(const U3DLoss& L, const float* __restrict__ bg) {
+  const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+  return LossCtx{L.kind, L.w_bg, L.w_non, b0, b1, b2, 1e-6f + 1e-5f * fabsf(b0), 1e-6f + 1e-5f * fabsf(b1), 1e-6f + 1e-5f * fabsf(b2)};
 }
-__device__ __forceinline__ float loss_pixel(const U3DLoss& L, const float* __restrict__ bg, float g0, float g1, float g2,
-                                            float d0, float d1, float d2) {
-  if (L.kind == 3) return fabsf(d0) + fabsf(d1) + fabsf(d2);
-  return focal_weight(L, bg, g0, g1, g2) * (d0 * d0 + d1 * d1 + d2 * d2);
+__device__ __forceinline__ float loss_weight(const LossCtx& c, bool inside, float g0, float g1, float g2) {
+  float w = 1.f;
+  if (c.kind == 2) {   // focal: background pixels of the target weigh w_bg, the others w_non
+    const bool is_bg = fabsf(g0 - c.b0) <= c.t0 && fabsf(g1 - c.b1) <= c.t1 && fabsf(g2 - c.b2) <= c.t2;
+    w = is_bg ? c.w_bg : c.w_non;
+  }
+  return inside ? w : 0.f;
+}
+__device__ __forceinline__ float loss_term(const LossCtx& c, float w, float d0, float d1, float d2) {
+  if (c.kind == 3) return w * (fabsf(d0) + fabsf(d1) + fabsf(d2));
+  return w * (d0 * d0 + d1 * d1 + d2 * d2);
+}
+// dL/dC of the pixel, sc = dL/dloss / count
+__device__ __forceinline__ void loss_seed(const LossCtx& c, float w, float sc, float d0, float d1, float d2, float& dp0, float& dp1, float& dp2) {
+  if (c.kind == 3) {
+    const float s = sc * w;
+    dp0 = s * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
+    dp1 = s * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+    dp2 = s * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
+  } else {
+    const float w2 = 2.f * sc * w;
+    dp0 = w2 * d0; dp1 = w2 * d1; dp2 = w2 * d2;
+  }
 }
 
 
@@ -452,32 +474,24 @@ __device__ __forceinline__ void store4(float* __restrict__ p, bool vec, const bo
   }
 }
 
-// dL/dC of the fused render loss for one pixel (utils/loss_utils.py:17-45), sc = dL/dloss / count
-__device__ __forceinline__ void loss_seed(const U3DLoss& loss, const float* __restrict__ bg, float sc, float g0, float g1, float g2,
-                                          float d0, float d1, float d2, float& dp0, float& dp1, float& dp2) {
-  if (loss.kind == 3) {
-    dp0 = sc * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
-    dp1 = sc * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
-    dp2 = sc * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
-  } else {
-    const float w2 = 2.f * sc * focal_weight(loss, bg, g0, g1, g2);
-    dp0 = w2 * d0; dp1 = w2 * d1; dp2 = w2 * d2;
-  }
-}
-
 // The tile kernels carry two loop variants each (PLAIN and not); left alone, the register allocator takes 75-77 VGPRs for the pair
 // (6 waves per SIMD).  For the single-pass kernel, pinning 8 waves per SIMD (64 VGPRs) spills a handful of values around the rarely
 // taken variant and measured 3 % faster than the unpinned build, 4.5 % faster than the single-variant kernel; the two-pass kernels
 // measured slower pinned (forward 97 against 87 us at C2) and are left to the allocator.
 #define U3D_FULL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(8, 8)))
+// Grid = (T tiles of a view, views [, view slabs of 65535]): the view index comes from the block id, the tile row from a host-made
+// magic multiplier (`tile_magic`, 0 = divide), so the prologue has no integer division.  Workgroups are dispatched to the XCDs
+// round-robin in linear order x + T * view, which is what u3d_xcd_chunk_in_view assumes.
+static_assert(TILE_WAVES == 1, "one wave = one workgroup = one tile");
 #define U3D_TILE_PROLOGUE(NWAVES)                                                                       \
-  const int tid = threadIdx.x, wave = (NWAVES) == 1 ? 0 : tid >> 6, lane = tid & 63; /* 1: all ids scalar */ \
-  const uint32_t lid = (NWAVES) == 1 ? u3d_xcd_remap_view(blockIdx.x, (uint32_t)T)                     \
-                                     : u3d_xcd_remap(blockIdx.x, nblocks) * (uint32_t)(NWAVES) + (uint32_t)wave; \
-  if (lid >= ntiles_total) return; /* whole wave leaves; there is no workgroup barrier below */         \
-  const int view = (int)(lid / T);                                                                      \
-  const int tile = (int)lid - view * T;                                                                 \
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;                                              \
+  const int lane = threadIdx.x, wave = 0;                                                               \
+  const uint32_t view_u = blockIdx.y + gridDim.y * blockIdx.z;                                          \
+  if (view_u * (uint32_t)T >= ntiles_total) return; /* (partial last slab) */                           \
+  const int view = (int)view_u;                                                                         \
+  const int tile = (int)u3d_xcd_chunk_in_view(blockIdx.x, view_u, (uint32_t)T);                         \
+  const uint32_t lid = view_u * (uint32_t)T + (uint32_t)tile;                                           \
+  const int ty = tile_magic ? (int)__umulhi((uint32_t)tile, tile_magic) : tile / tiles_x;               \
+  const int tx = tile - ty * tiles_x;                                                                   \
   const int py = ty * U3D_TILE + (lane >> 2);                                                           \
   const int px0 = tx * U3D_TILE + 4 * (lane & 3);                                                       \
   const float pyf = (float)py;                                                                          \
@@ -495,7 +509,7 @@ __device__ __forceinline__ void loss_seed(const U3DLoss& loss, const float* __re
 
 // ---- forward (operator path): colour, inverse depth, and the state the backward kernel restarts from --------
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
-    int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t nblocks, const uint32_t* __restrict__ sorted_id,
+    int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, const uint32_t* __restrict__ sorted_id,
     const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis, const float2* __restrict__ xy,
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
@@ -529,9 +543,10 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
     load4(loss.gt + cid0, vec, inside, g0);
     load4(loss.gt + cid0 + npix, vec, inside, g1);
     load4(loss.gt + cid0 + 2 * npix, vec, inside, g2);
+    const LossCtx lc = loss_ctx(loss, bg);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (inside[k]) e += loss_pixel(loss, bg, g0[k], g1[k], g2[k], o0[k] - g0[k], o1[k] - g1[k], o2[k] - g2[k]);
+      e += loss_term(lc, loss_weight(lc, inside[k], g0[k], g1[k], g2[k]), o0[k] - g0[k], o1[k] - g1[k], o2[k] - g2[k]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
     if (lane == 0) loss.partial[lid] = e;
@@ -541,7 +556,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
 // ---- backward (operator path, and second pass of the two-pass fused loss) ------------------------------------
 template <bool HAS_INVD, int PB>
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
-    int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t nblocks, size_t NG,
+    int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, size_t NG,
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const float2* __restrict__ xy,
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_dinvdepth, const float* __restrict__ final_T,
@@ -569,10 +584,11 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
     load4(loss.gt + cid0 + npix, vec, inside, g1);
     load4(loss.gt + cid0 + 2 * npix, vec, inside, g2);
     const float sc = loss.dloss[0] * loss.inv_count;
+    const LossCtx lc = loss_ctx(loss, bg);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      dp0[k] = dp1[k] = dp2[k] = dinv[k] = 0.f;
-      if (inside[k]) loss_seed(loss, bg, sc, g0[k], g1[k], g2[k], x0[k] - g0[k], x1[k] - g1[k], x2[k] - g2[k], dp0[k], dp1[k], dp2[k]);
+      dinv[k] = 0.f;
+      loss_seed(lc, loss_weight(lc, inside[k], g0[k], g1[k], g2[k]), sc, x0[k] - g0[k], x1[k] - g1[k], x2[k] - g2[k], dp0[k], dp1[k], dp2[k]);
     }
   } else {
     load4(dL_dcolor + cid0, vec, inside, dp0);
@@ -604,7 +620,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
 // disappears.  dL/dloss is taken as 1 (the result is linear in it; the host scales the stored gradient).
 template <int PB>
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void render_fb_wave_kernel(
-    int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t nblocks, size_t NG,
+    int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, size_t NG,
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis,
     const float2* __restrict__ xy, const float4* __restrict__ conic_op, const float4* __restrict__ rgbd,
     const float* __restrict__ bg, float* __restrict__ out_color, double* __restrict__ acc, float* __restrict__ part,
@@ -636,16 +652,15 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
     store4(out_color + cid0 + npix, vec, inside, o1);
     store4(out_color + cid0 + 2 * npix, vec, inside, o2);
   }
+  const LossCtx lc = loss_ctx(loss, bg);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    dp0[k] = dp1[k] = dp2[k] = dinv[k] = 0.f;
-    if (inside[k]) {
-      const float d0 = o0[k] - g0[k], d1 = o1[k] - g1[k], d2 = o2[k] - g2[k];
-      e += loss_pixel(loss, bg, g0[k], g1[k], g2[k], d0, d1, d2);
-      loss_seed(loss, bg, loss.inv_count, g0[k], g1[k], g2[k], d0, d1, d2, dp0[k], dp1[k], dp2[k]);   // dL/dloss == 1
-    } else {
-      F.Tr[k] = 0.f;
-    }
+    const float d0 = o0[k] - g0[k], d1 = o1[k] - g1[k], d2 = o2[k] - g2[k];
+    const float wk = loss_weight(lc, inside[k], g0[k], g1[k], g2[k]);
+    e += loss_term(lc, wk, d0, d1, d2);
+    loss_seed(lc, wk, loss.inv_count, d0, d1, d2, dp0[k], dp1[k], dp2[k]);   // dL/dloss == 1
+    dinv[k] = 0.f;
+    F.Tr[k] = inside[k] ? F.Tr[k] : 0.f;
     Rk[k] = F.Tr[k] * (bg[0] * dp0[k] + bg[1] * dp1[k] + bg[2] * dp2[k]);   // T_final * (bg . dL/dC)
   }
 #pragma unroll
@@ -890,15 +905,26 @@ void u3d_launch_loss_reduce(int n, const float* partial, float inv_count, float*
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, n, partial, inv_count, loss_out);
 }
 
+// launch shape of the tile kernels (see U3D_TILE_PROLOGUE)
+struct TileGrid { dim3 grid; uint32_t magic; };
+static inline TileGrid tile_grid(const u3d_raster_desc& d, int tiles_x, int T) {
+  const uint32_t NV = (uint32_t)(d.n_items * d.views_per_item);
+  const uint32_t gy = NV < 65535u ? NV : 65535u, gz = (NV + gy - 1u) / gy;
+  // ty = (tile * magic) >> 32 is exact for every tile < T when T * tiles_x < 2^32 (error term (magic * tiles_x - 2^32) < tiles_x)
+  uint32_t magic = 0u;
+  if (tiles_x > 1 && (uint64_t)T * (uint64_t)tiles_x < (1ull << 32)) magic = (uint32_t)(((1ull << 32) + (uint64_t)tiles_x - 1ull) / (uint64_t)tiles_x);
+  return TileGrid{dim3((uint32_t)T, gy, gz), magic};
+}
+
 void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,
                            float* out_invdepth, const U3DLoss& loss, hipStream_t s) {
   const int tiles_x = (d.image_width + U3D_TILE - 1) / U3D_TILE, tiles_y = (d.image_height + U3D_TILE - 1) / U3D_TILE;
   const int T = tiles_x * tiles_y;
   const uint32_t ntiles = (uint32_t)(d.n_items * d.views_per_item * T);
   if (ntiles == 0) return;
-  const uint32_t nwg = (ntiles + TILE_WAVES - 1u) / TILE_WAVES;
-  hipLaunchKernelGGL(render_fwd_wave_kernel, dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
-                     tiles_x, T, ntiles, nwg, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
+  const TileGrid tg = tile_grid(d, tiles_x, T);
+  hipLaunchKernelGGL(render_fwd_wave_kernel, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
+                     tiles_x, T, ntiles, tg.magic, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
                      out_invdepth, b.final_T, b.n_contrib, b.tile_last, loss);
 }
 
@@ -909,14 +935,14 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
   const uint32_t ntiles = (uint32_t)(d.n_items * d.views_per_item * T);
   const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
   if (ntiles == 0 || NG == 0) return;
-  const uint32_t nwg = (ntiles + TILE_WAVES - 1u) / TILE_WAVES;
+  const TileGrid tg = tile_grid(d, tiles_x, T);
   if (u3d_part_blocks(d) == 1)
-    hipLaunchKernelGGL(render_fb_wave_kernel<1>, dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
-                       tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
+    hipLaunchKernelGGL(render_fb_wave_kernel<1>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
+                       tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
                        acc, part, b.clamped, loss);
   else
-    hipLaunchKernelGGL(render_fb_wave_kernel<U3D_PART_BLOCKS>, dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height,
-                       d.image_width, tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg,
+    hipLaunchKernelGGL(render_fb_wave_kernel<U3D_PART_BLOCKS>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height,
+                       d.image_width, tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg,
                        out_color, acc, part, b.clamped, loss);
   const int nsplit = bwd_reduce_split(T);
   auto* reduce_k = u3d_part_blocks(d) == 1 ? bwd_reduce1_kernel : bwd_reduce_kernel<U3D_PART_BLOCKS>;
@@ -934,11 +960,11 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   const uint32_t ntiles = (uint32_t)(d.n_items * d.views_per_item * T);
   const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
   if (ntiles == 0 || NG == 0) return;
-  const uint32_t nwg = (ntiles + TILE_WAVES - 1u) / TILE_WAVES;
+  const TileGrid tg = tile_grid(d, tiles_x, T);
   const bool invd = dL_dinvdepth && loss.kind == 0;
 #define LAUNCH(INVD, PBV)                                                                                                   \
-  hipLaunchKernelGGL((render_bwd_wave_kernel<INVD, PBV>), dim3(nwg), dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, \
-                     d.image_width, tiles_x, T, ntiles, nwg, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg,    \
+  hipLaunchKernelGGL((render_bwd_wave_kernel<INVD, PBV>), tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, \
+                     d.image_width, tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg,    \
                      dL_dcolor, dL_dinvdepth, b.final_T, b.n_contrib, b.tile_last, acc, part, out_color, b.clamped, loss)
   if (u3d_part_blocks(d) == 1) { if (invd) LAUNCH(true, 1); else LAUNCH(false, 1); }
   else { if (invd) LAUNCH(true, U3D_PART_BLOCKS); else LAUNCH(false, U3D_PART_BLOCKS); }
