@@ -313,7 +313,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     conic_op[g] = co;
     rgbd[g] = col;
     rect[g] = rc;
-    clamped[g] = cb;
+    clamped[g] = cb;   // (every pair is written, culled ones too: skipping them turns full-line stores into scattered partial lines -- measured 86 against 46 us at C5)
     if (radius > 0) sort_key = ((unsigned long long)__float_as_uint(zv) << 32) | (uint32_t)i;
     sort_rect = rc;
     if (acc_zero) {   // single-pass training step: clear this (view, Gaussian)'s gradient accumulators here (saves a memset node)
@@ -371,6 +371,49 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
   const int i = blockIdx.x * (U3D_BLOCK / 4) + (threadIdx.x >> 2);
   const bool alive = i < P;
   const size_t gi = (size_t)item * P + (alive ? i : 0);
+  constexpr int K = (D + 1) * (D + 1);
+  const bool writer = alive && vslot == 0;
+  float qd[4] = {0.f, 0.f, 0.f, 0.f};
+  // Does any view hand a Gaussian of this wave a gradient?  At scene level almost none does (a pixel saturates after a few dozen
+  // of the view's 10^5 sorted entries): such a wave writes its zeros and skips the parameter loads, the activations and Sigma.
+  bool lane_live = false;
+  for (int vk = vslot; vk < (alive ? vpi : 0); vk += 4) {
+    const size_t g = (size_t)(item * vpi + vk) * P + i;
+    lane_live = lane_live || (radii[g] > 0 && (clamped[g] & U3D_TOUCHED_BIT) != 0u);
+  }
+  if (__ballot(lane_live) == 0ull) {
+    if (sink.means2D) {
+      for (int vk = vslot; vk < (alive ? vpi : 0); vk += 4) {
+        const size_t g = (size_t)(item * vpi + vk) * P + i;
+        sink.means2D[g * 3] = 0.f; sink.means2D[g * 3 + 1] = 0.f; sink.means2D[g * 3 + 2] = 0.f;
+      }
+    }
+    if (src.act != 0) {
+      // fused mode: the gradient rows of the wave's 16 Gaussians are 16 * C consecutive floats of d(head output)
+      const int C = src.s_means, iw = blockIdx.x * (U3D_BLOCK / 4) + (threadIdx.x >> 6) * 16, n = min(16, P - iw) * C;
+      float* o = sink.means + ((size_t)item * P + iw) * C;
+      for (int e = threadIdx.x & 63; e < n; e += 64) o[e] = 0.f;
+    } else if (writer) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sink.means[gi * src.s_means + k] = 0.f;
+      sink.opac[gi * src.s_opac] = 0.f;
+      if (sink.colors) { sink.colors[gi * 3] = 0.f; sink.colors[gi * 3 + 1] = 0.f; sink.colors[gi * 3 + 2] = 0.f; }
+      if (sink.cov) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sink.cov[gi * 6 + k] = 0.f;
+      }
+      if (sink.shs) {
+        float* o = sink.shs + gi * (size_t)src.s_shs;
+        for (int k = 0; k < M * 3; ++k) o[k] = 0.f;
+      }
+      if (sink.scales) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sink.scales[gi * src.s_scales + k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sink.rots[gi * src.s_rots + k] = 0.f;
+      }
+    }
+  } else {
   GaussIn gin;
   load_gaussian(src, item, gi, gin);
   const float* p = gin.p;
@@ -386,7 +429,6 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     cov3d_from_scale_rot(s, mod, q, c6);
   }
   const float op_in = gin.op;
-  constexpr int K = (D + 1) * (D + 1);
   float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
   float dsh[K * 3];
 #pragma unroll
@@ -561,7 +603,6 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
 #pragma unroll
   for (int k = 0; k < K * 3; ++k) QUAD_SUM(dsh[k]);
 #undef QUAD_SUM
-  const bool writer = alive && vslot == 0;
 
   // ---- outputs (strided like the source); act != 0 chains through the head activations ----
   float drot[4] = {0.f, 0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f};
@@ -595,7 +636,6 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     drot[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
     drot[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
   }
-  float qd[4] = {0.f, 0.f, 0.f, 0.f};
   if (writer) {
     if (src.act != 0) {
       // tanh, sigmoid, exp(clamp) derivatives (model/gaussian_predictor.py:249-254)
@@ -639,6 +679,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
 #pragma unroll
       for (int k = 0; k < 4; ++k) sink.rots[gi * src.s_rots + k] = drot[k];
     }
+  }
   }
   if (src.act == 1) {
     // block reduction of sum_i raw_q[i][c] * g[i][c]; one atomic per block and component

@@ -122,7 +122,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 constexpr int BWD_PART_STRIDE = U3D_PART_STRIDE;   // floats per tile: [U3D_PART_BLOCKS][64 positions][10], the LDS rows as they are
 // bwd_reduce_kernel: workgroups per view.  The slices of a view meet in f64 atomics (cost ~ slices), the tile chain of a
 // slice is latency-bound (cost ~ tiles per slice): ~128 tiles per slice measured best (C2: 10.4 us with 2 slices, 17 with 8).
-static inline int bwd_reduce_split(int T) { const int s = (T + 64) / 128; return s < 1 ? 1 : (s > 32 ? 32 : s); }
+// With few views (scene level: 8-16) that alone leaves most CUs idle, so the slice count also grows until ~256 workgroups exist.
+static inline int bwd_reduce_split(int T, int NV) {
+  int s = (T + 64) / 128;
+  const int fill = NV > 0 ? 256 / NV : 1;
+  if (s < fill) s = fill;
+  if (s > T / 8) s = T / 8;
+  return s < 1 ? 1 : (s > 32 ? 32 : s);
+}
 constexpr int TILE_WAVES = 1;   // tiles per workgroup: one (finer-grained dispatch measured 8 % faster than four)
 
 struct TileLds {   // wave-private; 2560 B of staged entries + 2560 B of gradient rows = 5 KB per wave -> 32 waves per CU
@@ -962,7 +969,7 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
     hipLaunchKernelGGL(render_fb_wave_kernel<U3D_PART_BLOCKS>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height,
                        d.image_width, tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg,
                        out_color, acc, part, b.clamped, loss);
-  const int nsplit = bwd_reduce_split(T);
+  const int nsplit = bwd_reduce_split(T, d.n_items * d.views_per_item);
   auto* reduce_k = u3d_part_blocks(d) == 1 ? bwd_reduce1_kernel : bwd_reduce_kernel<U3D_PART_BLOCKS>;
   hipLaunchKernelGGL(reduce_k, dim3(d.n_items * d.views_per_item, nsplit + 1), dim3(REDUCE_THREADS), 0, s,
                      d.P, T, U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id, b.conic_op, part,
@@ -987,7 +994,7 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   if (u3d_part_blocks(d) == 1) { if (invd) LAUNCH(true, 1); else LAUNCH(false, 1); }
   else { if (invd) LAUNCH(true, U3D_PART_BLOCKS); else LAUNCH(false, U3D_PART_BLOCKS); }
 #undef LAUNCH
-  const int nsplit = bwd_reduce_split(T);
+  const int nsplit = bwd_reduce_split(T, d.n_items * d.views_per_item);
   auto* reduce_k = u3d_part_blocks(d) == 1 ? bwd_reduce1_kernel : bwd_reduce_kernel<U3D_PART_BLOCKS>;
   hipLaunchKernelGGL(reduce_k, dim3(d.n_items * d.views_per_item, nsplit), dim3(REDUCE_THREADS), 0, s,
                      d.P, T, invd ? U3D_NACC : U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id,
