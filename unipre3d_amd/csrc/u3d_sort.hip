@@ -12,7 +12,8 @@
 //  * larger P: 4-pass LSD radix sort (8-bit digits) on the depth bits with the index as payload;
 //    LSD passes are stable and the initial order is index order, so ties resolve by index.  Per pass: per-block digit
 //    histogram, then a scatter whose prologue turns the histograms into its own offsets (no separate scan launch) and
-//    ranks keys with ballot multi-split (8 ballots per key, stable within the wave, waves ordered through LDS).
+//    ranks keys with ballot multi-split (8 ballots per key, stable within the wave, waves ordered through LDS); the last
+//    pass writes the sorted ids and their tile rectangles directly.
 #include "u3d_common.h"
 
 namespace {
@@ -159,7 +160,8 @@ __global__ __launch_bounds__(NT) void radix_scatter_kernel(int pass, int P, int 
                                                            const int32_t* __restrict__ radii, const uint32_t* __restrict__ keys_in,
                                                            const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
                                                            uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ hist,
-                                                           uint32_t* __restrict__ n_vis) {
+                                                           uint32_t* __restrict__ n_vis, const uint2* __restrict__ rect,
+                                                           uint32_t* __restrict__ sorted_id, uint2* __restrict__ sorted_rect) {
   constexpr int NW = NT / 64;
   __shared__ uint32_t digit_base[256];
   __shared__ uint32_t wave_cnt[2][NW][256];   // double-buffered per round: counts, then exclusive prefixes over the waves
@@ -169,6 +171,12 @@ __global__ __launch_bounds__(NT) void radix_scatter_kernel(int pass, int P, int 
   const uint32_t lane = u3d_lane_id();
   const size_t base = (size_t)view * P;
   const int limit = pass == 0 ? P : (int)n_vis[view];
+  if (pass == 3) {
+    // the last pass writes the sorted list itself (ids and their tile rectangles; no separate gather launch); positions past the
+    // visible keys read id 0 / empty rectangle
+    for (int idx = blk * (ITEMS * NT) + tid; idx < min(P, (blk + 1) * (ITEMS * NT)); idx += NT)
+      if (idx >= limit) { sorted_id[base + idx] = 0u; sorted_rect[base + idx] = make_uint2(0u, 0u); }
+  }
   if (blk * (ITEMS * NT) >= limit) return;   // whole workgroup past the visible keys (uniform)
   for (int e = tid; e < 2 * NW * 256; e += NT) (&wave_cnt[0][0][0])[e] = 0;
   {
@@ -235,27 +243,17 @@ __global__ __launch_bounds__(NT) void radix_scatter_kernel(int pass, int P, int 
     __syncthreads();
     if (valid) {
       const uint32_t dst = cnt[wave][digit] + rank;
-      keys_out[base + dst] = k;
-      vals_out[base + dst] = v;
+      if (pass == 3) {
+        sorted_id[base + dst] = v;
+        sorted_rect[base + dst] = rect[base + v];
+      } else {
+        keys_out[base + dst] = k;
+        vals_out[base + dst] = v;
+      }
     }
     for (int e = tid; e < NW * 256; e += NT) (&wave_cnt[(r + 1) & 1][0][0])[e] = 0;   // the other buffer, for the next round
     __syncthreads();
   }
-}
-
-__global__ __launch_bounds__(U3D_BLOCK) void radix_finalize_kernel(int P, const uint32_t* __restrict__ vals,
-                                                                   const uint2* __restrict__ rect,
-                                                                   uint32_t* __restrict__ sorted_id,
-                                                                   uint2* __restrict__ sorted_rect,
-                                                                   const uint32_t* __restrict__ n_vis) {
-  const int view = blockIdx.y;
-  const int i = blockIdx.x * U3D_BLOCK + threadIdx.x;
-  if (i >= P) return;
-  const size_t base = (size_t)view * P;
-  const bool vis = (uint32_t)i < n_vis[view];
-  const uint32_t id = vis ? vals[base + i] : 0u;
-  sorted_id[base + i] = id;
-  sorted_rect[base + i] = vis ? rect[base + id] : make_uint2(0u, 0u);
 }
 
 }  // namespace
@@ -294,12 +292,9 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
     hipLaunchKernelGGL((radix_hist_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), 0, s, pass, d.P, nblk, b.depth, radii, kin,    \
                        b.n_vis, b.sort_hist);                                                                                \
     hipLaunchKernelGGL((radix_scatter_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), 0, s, pass, d.P, nblk, b.depth, radii, kin, \
-                       vin, kout, vout, b.sort_hist, b.n_vis);                                                               \
+                       vin, kout, vout, b.sort_hist, b.n_vis, b.rect, b.sorted_id, b.sorted_rect);                           \
   } while (0)
     if (d.P <= 65536) LAUNCH(U3D_RADIX_NT_SMALL, U3D_RADIX_IT_SMALL); else LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE);
 #undef LAUNCH
   }
-  // pass 3 wrote buffer index 1
-  hipLaunchKernelGGL(radix_finalize_kernel, dim3((d.P + U3D_BLOCK - 1) / U3D_BLOCK, NV), dim3(U3D_BLOCK), 0, s, d.P,
-                     b.sort_vals[1], b.rect, b.sorted_id, b.sorted_rect, b.n_vis);
 }
