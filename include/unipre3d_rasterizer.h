@@ -69,7 +69,8 @@ typedef struct u3d_raster_desc {
 typedef struct u3d_scratch_sizes {
   size_t geom_bytes;     /* per (view, Gaussian) projected state  ("geomBuffer")              */
   size_t binning_bytes;  /* depth-sorted ids / tile rects / sort temporaries ("binningBuffer") */
-  size_t image_bytes;    /* per-pixel final transmittance + position limit, per-tile last contributor ("imgBuffer") */
+  size_t image_bytes;    /* per-pixel final transmittance + position limit, per-tile last contributor (bit 31: loop variant the
+                            forward took, read back by the backward) ("imgBuffer") */
   size_t backward_bytes; /* per (view, Gaussian) screen-space gradient accumulators           */
   size_t num_rendered_offset; /* byte offset inside geom of uint32 num_rendered[n_views] (U3D_FLAG_STATS) */
   size_t fused_bytes;    /* u3d_render_loss_*: quaternion norms/dots + per-tile loss partials  */
