@@ -82,6 +82,35 @@ def test_large_P_radix_sort_path(oracle_mod, P, level, compact):
         assert rel_l2(g[k].reshape(go[k].shape), go[k]) < TOL, k
 
 
+@pytest.mark.parametrize("F", [4096.0, 2097152.0])
+def test_radix_sort_far_depths(oracle_mod, F):
+    """Depth keys far from the unit range: the whole scene scaled by a power of two F (positions, extents, camera translation: the
+    image and every rounding are unchanged, every depth is F times larger), so that the radix digits that are constant in ordinary
+    scenes (the top byte of the depth bits) vary here."""
+    sc = scene(6000, 64, 80, seed=6, level="scene", compact=True, deg=1)
+    V = sc["viewmatrix"].double()
+    Pm = torch.linalg.inv(V) @ sc["projmatrix"].double()          # projmatrix = viewmatrix @ Pm (row-vector convention)
+    V2 = V.clone(); V2[3, :3] *= F                                # p_view' = F p_view for p' = F p
+    z0 = torch.cat([sc["means3D"].double(), torch.ones(6000, 1, dtype=torch.float64)], 1) @ V[:, 2]
+    too_near = (z0 > 0) & (z0 <= 0.25)                              # the near cull stays at 0.2: these would turn into giant splats
+    sc["means3D"][too_near] -= ((z0[too_near] + 1.0)[:, None] * V[:3, 2][None, :]).float()    # ... put them behind the camera
+    sc["means3D"] = sc["means3D"] * F
+    sc["scales"] = sc["scales"] * F
+    sc["campos"] = sc["campos"] * F
+    sc["viewmatrix"] = V2.float().contiguous()
+    sc["projmatrix"] = (V2 @ Pm).float().contiguous()
+    sc["means3D"][200:230] = sc["means3D"][200]                   # depth ties resolve by index on this path too
+    dcol, dinv = cotangents(64, 80)
+    color, invd, radii, g = _run_gpu(sc, dcol, dinv)
+    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
+    zv = (np.c_[to_numpy(sc)["means3D"].astype(np.float64), np.ones(6000)] @ V2.numpy())[:, 2]
+    assert zv[r.radii > 0].min() > 0.2 * F and zv[r.radii > 0].max() > 4.0 * zv[r.radii > 0].min()
+    assert np.array_equal(radii, r.radii) and near(color, r.color, r64.color)
+    go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
+    for k in DIFF_KEYS:
+        assert near(g[k].reshape(go[k].shape), go[k], go64[k]), k
+
+
 def test_depth_ties_small_P(oracle_mod):
     sc = scene(200, 64, 96, seed=4, compact=True)
     sc["means3D"][10:40] = sc["means3D"][10]
