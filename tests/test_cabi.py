@@ -101,28 +101,49 @@ def test_product_never_imports_oracle():
     assert "oracle" not in src
 
 
+def _xcd_chunk_in_view(j, view, T):
+    """Host restatement of `u3d_xcd_chunk_in_view` (unipre3d_amd/csrc/u3d_common.h): the tile kernels run a (T, views) grid; the
+    workgroup with x index j of view `view` has linear id view*T + j and sits on XCD (view*T + j) % 8; within a view the blocks of
+    residue class x are numbered in order and mapped to the x-th chunk of the view's tile range."""
+    below = lambda n, c: (n >> 3) * c + min(n & 7, c)
+    r = (view * T) & 7
+    m = r + j
+    x = m & 7
+    k = ((m + 7 - x) >> 3) - ((r + 7 - x) >> 3)
+    return (below(r + T, x) - below(r, x)) + k
+
+
 def test_xcd_view_chunk_mapping_is_a_bijection():
-    """Host restatement of `u3d_xcd_remap_view` (unipre3d_amd/csrc/u3d_common.h): workgroup b sits on XCD b % 8; within each
-    view the blocks of one residue class must map, in order, onto one contiguous chunk of that view's tiles, and the whole
-    map must be a bijection for ANY tile count (the kernels index per-tile scratch with it)."""
-    def below(n, c):
-        return (n >> 3) * c + min(n & 7, c)
+    for T, nv in ((256, 128), (1200, 16), (64, 8), (1, 5), (2, 3), (7, 9), (8, 4), (9, 4), (13, 3), (15, 8), (63, 3), (70, 3), (1000, 2)):
+        seen = set()
+        for v in range(nv):
+            per_xcd = [[] for _ in range(8)]
+            for j in range(T):
+                t = _xcd_chunk_in_view(j, v, T)
+                assert 0 <= t < T, (T, v, j, t)
+                seen.add(v * T + t)
+                per_xcd[(v * T + j) % 8].append(t)
+            sizes = [len(c) for c in per_xcd]
+            assert max(sizes) - min(sizes) <= 1                 # each XCD renders ~1/8 of every view
+            for c in per_xcd:                                   # ... as one contiguous chunk of the view's tiles, in order
+                assert c == list(range(c[0], c[0] + len(c))) if c else True
+        assert len(seen) == T * nv                              # every tile of every view exactly once (any T: per-tile scratch is indexed by it)
 
-    def remap(b, T):
-        view = b // T
-        j = b - view * T
-        r = (view * T) & 7
-        m = r + j
-        x = m & 7
-        k = ((m + 7 - x) >> 3) - ((r + 7 - x) >> 3)
-        return view * T + (below(r + T, x) - below(r, x)) + k
 
-    for T in (1, 2, 3, 7, 8, 9, 12, 15, 16, 20, 63, 64, 70, 256, 1200):
-        for nv in (1, 3, 8):
-            out = [remap(b, T) for b in range(nv * T)]
-            assert sorted(out) == list(range(nv * T)), (T, nv)
-            for v in range(nv):
-                for x in range(8):
-                    tiles = [out[b] for b in range(v * T, (v + 1) * T) if b % 8 == x]
-                    assert tiles == list(range(tiles[0], tiles[0] + len(tiles))) if tiles else True   # contiguous, in order
-                    assert all(v * T <= t < (v + 1) * T for t in tiles)
+def test_tile_row_magic_multiplier_is_exact():
+    """Host restatement of `tile_grid` (unipre3d_amd/csrc/u3d_render.hip): the tile kernels find a tile's row as
+    (tile * magic) >> 32 with magic = ceil(2^32 / tiles_x), used only when T * tiles_x < 2^32 (else they divide)."""
+    import random
+    rnd = random.Random(3)
+    shapes = [(16, 16), (40, 30), (2, 1), (3, 7), (1024, 1024), (511, 513), (65535, 1), (4096, 255)]
+    for tiles_x, tiles_y in shapes:
+        T = tiles_x * tiles_y
+        if tiles_x == 1 or T * tiles_x >= 1 << 32:
+            continue                                            # magic = 0: the kernel divides
+        magic = ((1 << 32) + tiles_x - 1) // tiles_x
+        assert magic < 1 << 32
+        probes = {0, 1, tiles_x - 1, tiles_x, T - 1, T - tiles_x, T // 2} | {rnd.randrange(T) for _ in range(2000)}
+        probes |= {y * tiles_x + dx for y in (0, tiles_y - 1, tiles_y // 2) for dx in (-1, 0, 1)}
+        for tile in probes:
+            if 0 <= tile < T:
+                assert (tile * magic) >> 32 == tile // tiles_x, (tiles_x, tiles_y, tile)
