@@ -53,7 +53,7 @@ extern "C" {
 #define U3D_ERR_NO_DEVICE 4
 
 typedef struct u3d_raster_desc {
-  int32_t n_items;        /* independent Gaussian sets (objects / scenes) in this call        */
+  int32_t n_items;        /* independent Gaussian sets (objects / scenes) in this call, <= 65535 */
   int32_t views_per_item; /* cameras per set; n_views = n_items * views_per_item               */
   int32_t P;              /* Gaussians per set                                                 */
   int32_t image_height;   /* settings field 1                                                  */

@@ -147,3 +147,16 @@ def test_tile_row_magic_multiplier_is_exact():
         for tile in probes:
             if 0 <= tile < T:
                 assert (tile * magic) >> 32 == tile // tiles_x, (tiles_x, tiles_y, tile)
+
+
+def test_scratch_query_rejects_unsupported_shapes():
+    """Host-side validation (no GPU work): more than 65535 Gaussian sets per call is reported as unsupported, not launched."""
+    import ctypes
+    from unipre3d_amd import _lib
+    lib = _lib.load()
+    d = _lib.RasterDesc(n_items=65536, views_per_item=1, P=4, image_height=16, image_width=16, tanfovx=0.5, tanfovy=0.5,
+                        scale_modifier=1.0, sh_degree=1, sh_coeffs=4, flags=0)
+    sizes = _lib.ScratchSizes()
+    assert lib.u3d_scratch_query(ctypes.byref(d), ctypes.byref(sizes)) == 2      # U3D_ERR_UNSUPPORTED
+    d.n_items = 65535
+    assert lib.u3d_scratch_query(ctypes.byref(d), ctypes.byref(sizes)) == 0
