@@ -37,7 +37,8 @@ struct ProfScope {
 int check_desc(const u3d_raster_desc* d) {
   if (!d) return U3D_ERR_INVALID_ARGUMENT;
   if (d->n_items < 0 || d->views_per_item < 0 || d->P < 0) return U3D_ERR_INVALID_ARGUMENT;
-  if (d->n_items > 65535) return U3D_ERR_UNSUPPORTED;   // items are a grid y dimension of the per-Gaussian kernels (views are not limited)
+  if (d->n_items > 65535) return U3D_ERR_UNSUPPORTED;   // items are a grid y dimension of the per-Gaussian kernels
+  if (d->P > U3D_LDS_SORT_MAX && (long long)d->n_items * d->views_per_item > 65535) return U3D_ERR_UNSUPPORTED;   // (so are the views of the radix passes)
   if (d->image_height <= 0 || d->image_width <= 0) return U3D_ERR_INVALID_ARGUMENT;
   if (d->image_height > 65535 * U3D_TILE || d->image_width > 65535 * U3D_TILE) return U3D_ERR_UNSUPPORTED;
   if (d->sh_degree < 0 || d->sh_degree > 3) return U3D_ERR_UNSUPPORTED;
