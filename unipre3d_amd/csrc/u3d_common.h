@@ -10,6 +10,7 @@
 #define U3D_WAVE 64
 // set in `clamped` by the gradient reduction for every (view, Gaussian) that received a non-zero row: preprocess_bwd reads the
 // 80 B of accumulators only for those (a pixel saturates after a few dozen entries, so most visible Gaussians get none)
+#define U3D_FLAG_INTERNAL_TRIAGE 0x40000000   /* (launcher -> preprocess_bwd only, never part of the ABI flags) */
 #define U3D_TOUCHED_BIT 0x80000000u
 #define U3D_TILE_PLAIN_BIT 0x80000000u   /* tile_last: the forward ran the loop variant without clamp / pw test */
 #define U3D_NACC 10         // mean2D.xy, conic(a, b/2, c), opacity, rgb, invdepth
@@ -225,6 +226,36 @@ __device__ __forceinline__ uint32_t u3d_xcd_chunk_in_view(uint32_t j, uint32_t v
 __device__ __forceinline__ uint32_t u3d_xcd_remap_view(uint32_t bid, uint32_t T) {   // linear form: bid = view * T + j
   const uint32_t view = bid / T;
   return view * T + u3d_xcd_chunk_in_view(bid - view * T, view, T);
+}
+
+// Sum over the 64 lanes by DPP (quad, half-row, row, then the two row broadcasts of GFX9); the total comes back wave-uniform.
+// (A shuffle butterfly costs six LDS round trips and ~40 address instructions.)
+__device__ __forceinline__ float u3d_wave_sum(float v) {
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// Sum over the 4 lanes of a DPP quad (all four lanes receive it): two v_add_f32_dpp instead of two LDS shuffles.
+__device__ __forceinline__ float u3d_quad_sum(float v) {
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "+v"(v));
+  return v;
 }
 
 __device__ __forceinline__ uint32_t u3d_lane_id() {

@@ -205,9 +205,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float v = a[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const float v = u3d_wave_sum(a[k]);
         if (lane == 0) s_qsm[wave][k] = v;
       }
       __syncthreads();
@@ -376,10 +374,14 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
   float qd[4] = {0.f, 0.f, 0.f, 0.f};
   // Does any view hand a Gaussian of this wave a gradient?  At scene level almost none does (a pixel saturates after a few dozen
   // of the view's 10^5 sorted entries): such a wave writes its zeros and skips the parameter loads, the activations and Sigma.
-  bool lane_live = false;
-  for (int vk = vslot; vk < (alive ? vpi : 0); vk += 4) {
-    const size_t g = (size_t)(item * vpi + vk) * P + i;
-    lane_live = lane_live || (radii[g] > 0 && (clamped[g] & U3D_TOUCHED_BIT) != 0u);
+  // (Only asked for at scene level, U3D_FLAG_INTERNAL_TRIAGE: at object level every Gaussian is live and the extra dependent
+  // load phase costs this latency-bound kernel ~1 us.)
+  bool lane_live = (flags & U3D_FLAG_INTERNAL_TRIAGE) == 0;
+  if (!lane_live) {
+    for (int vk = vslot; vk < (alive ? vpi : 0); vk += 4) {
+      const size_t g = (size_t)(item * vpi + vk) * P + i;
+      lane_live = lane_live || (radii[g] > 0 && (clamped[g] & U3D_TOUCHED_BIT) != 0u);
+    }
   }
   if (__ballot(lane_live) == 0ull) {
     if (sink.means2D) {
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
   }
 
   // ---- sum the quad's view slots (two xor steps inside the DPP quad) ----
-#define QUAD_SUM(v) do { (v) += __shfl_xor((v), 1); (v) += __shfl_xor((v), 2); } while (0)
+#define QUAD_SUM(v) do { (v) = u3d_quad_sum(v); } while (0)
 #pragma unroll
   for (int k = 0; k < 3; ++k) { QUAD_SUM(dmean[k]); QUAD_SUM(dcol[k]); }
 #pragma unroll
@@ -686,9 +688,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float v = qd[k];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      const float v = u3d_wave_sum(qd[k]);
       if (lane == 0) s_qdot[wave][k] = v;
     }
     __syncthreads();
@@ -713,9 +713,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void quat_norms_kernel(int P, const floa
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    float v = a[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float v = u3d_wave_sum(a[k]);
     if (lane == 0) sm[wave][k] = v;
   }
   __syncthreads();
@@ -782,9 +780,10 @@ void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, co
   const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
   dim3 grid((d.P + U3D_BLOCK / 4 - 1) / (U3D_BLOCK / 4), d.n_items), block(U3D_BLOCK);
   const int D = src.shs ? d.sh_degree : 0;
+  const int flags = d.flags | (d.P > U3D_LDS_SORT_MAX ? U3D_FLAG_INTERNAL_TRIAGE : 0);   // scene level: most waves only write zeros
 #define LAUNCH(DEG)                                                                                                    \
   hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, d.P, d.views_per_item, d.sh_coeffs, d.image_height, \
-                     d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, NG, src, viewmatrix, projmatrix,  \
+                     d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, flags, NG, src, viewmatrix, projmatrix,    \
                      campos, radii, b.clamped, acc, sink)
   switch (D) {
     case 0: LAUNCH(0); break;

@@ -83,26 +83,6 @@ __device__ __forceinline__ float min_099(float a) {   // fminf(0.99f, a) without
   return r;
 }
 
-// Sum over the 64 lanes by DPP (quad, half-row, row, then the two row broadcasts of GFX9); the total comes back wave-uniform.
-// (A shuffle butterfly costs six LDS round trips and ~40 address instructions per tile.)
-__device__ __forceinline__ float wave_sum(float v) {
-  asm volatile("s_nop 1\n\t"
-               "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-               "s_nop 1\n\t"
-               "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-               "s_nop 1\n\t"
-               "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-               "s_nop 1\n\t"
-               "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-               "s_nop 1\n\t"
-               "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-               "s_nop 1\n\t"
-               "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-               "s_nop 1"
-               : "+v"(v));
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
 // ---- tile machinery shared by the three compositing kernels -----------------------------------------
 // ONE WAVE owns one 16x16 tile.  Lane layout: lane>>2 is the tile ROW, the lane's 4 pixels are the consecutive COLUMNS
 // 4*(lane&3)+k, so image rows move as one 16-byte access per lane and channel, and a DPP quad (4 lanes) is one 16-pixel
@@ -574,7 +554,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       e += loss_term(lc, loss_weight(lc, inside[k], g0[k], g1[k], g2[k]), o0[k] - g0[k], o1[k] - g1[k], o2[k] - g2[k]);
-    e = wave_sum(e);
+    e = u3d_wave_sum(e);
     if (lane == 0) loss.partial[lid] = e;
   }
 }
@@ -689,7 +669,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
     F.Tr[k] = inside[k] ? F.Tr[k] : 0.f;
     Rk[k] = F.Tr[k] * (bg[0] * dp0[k] + bg[1] * dp1[k] + bg[2] * dp2[k]);   // T_final * (bg . dL/dC)
   }
-  e = wave_sum(e);
+  e = u3d_wave_sum(e);
   if (lane == 0) loss.partial[lid] = e;
 
   if (plain)
