@@ -98,7 +98,7 @@ __device__ __forceinline__ float min_099(float a) {   // fminf(0.99f, a) without
 //   * only m0, mx, mxx and the colour (depth) gradients are accumulated per pixel; after the two quad levels of the
 //     reduction  my = dy m0, mxy = dy mx, myy = dy my;
 //   * the half-row and row levels use DPP bank masks to deposit two values into one register per instruction pair
-//     (9-10 values -> 5 -> 3 registers), and the four rows of the wave meet in three LDS float adds.
+//     (9-10 values -> 5 -> 3 registers), and the four rows of the wave meet through the LDS crossbar (swizzle + bpermute).
 constexpr int BWD_PART_STRIDE = U3D_PART_STRIDE;   // floats per tile: [U3D_PART_BLOCKS][64 positions][10], the LDS rows as they are
 // bwd_reduce_kernel: workgroups per view.  The slices of a view meet in f64 atomics (cost ~ slices), the tile chain of a
 // slice is latency-bound (cost ~ tiles per slice): ~128 tiles per slice measured best (C2: 10.4 us with 2 slices, 17 with 8).
@@ -259,10 +259,10 @@ __device__ __forceinline__ T moment_to_acc(int k, const T* m, float a, float b, 
 // Back-to-front walk over sorted positions [1, wmax] of this tile: recovers T by division and
 // accumulates each Gaussian's gradients as MOMENTS of q = dL/dG * G over the pixel offsets,
 //     m0 = sum q, mx = sum q dx, my = sum q dy, mxx = sum q dx^2, mxy = sum q dx dy, myy = sum q dy^2.
-// Cross-tile accumulation without atomics in the common case: the first 64 positions of the view's sorted list -- where
+// Cross-tile accumulation without atomics in the common case: the first 64 (P <= 256) or 128 positions of the view's sorted list -- where
 // the reference's large, fairly opaque splats put essentially all contributions -- are written per tile to
 // part[tile][position][10] (the LDS rows as they are, only the rows the tile touched) and summed over the tiles in a FIXED order, in f64, by
-// bwd_reduce_kernel.  Only sorted positions >= 64 (sparse / semi-transparent scenes) fall back to f64 global atomics,
+// bwd_reduce_kernel.  Only sorted positions beyond those blocks (sparse / semi-transparent scenes) fall back to f64 global atomics,
 // whose ordering does not show at fp32 output precision (the original: one fp32 atomic per pixel and component).
 //   Tr = T_final, Rk = T_final (bg . dL/dC), lim = exclusive sorted-position limit per pixel (0: pixel takes no part).
 template <bool HAS_INVD, int PB /* partial-row blocks in use */, bool PLAIN /* every batch of the tile qualified in the forward pass */>
