@@ -15,6 +15,12 @@ for it in range(N):
     level = ("object", "scene")[int(rng.integers(0, 2))]; kind = ("focal_l2", "l2", "l1")[int(rng.integers(0, 3))]
     compact = bool(rng.integers(0, 2)); seed = int(rng.integers(0, 1 << 30))
     b = synthetic.make_batch(B, P, V, H, W, level=level, seed=seed, compact=compact).to(dev)
+    variant = int(rng.integers(0, 4))      # 1: some opacities sigmoid(6) (0.99 clamp live), 2: needles (nearly singular conics), 3: both
+    if variant & 1:
+        b.raw[:, 3, ::int(rng.integers(2, 9))] = 6.0
+    if variant & 2:
+        st = int(rng.integers(3, 11))
+        b.raw[:, 4, ::st] = 3.0; b.raw[:, 5, ::st] = -1.0; b.raw[:, 6, ::st] = -1.0
     res = []
     for sp in (True, False):
         h = b.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
@@ -34,8 +40,11 @@ for it in range(N):
     e12 = (res[0][2] - res[1][2]).abs().max().item() / gn
     e1u = rel_l2(res[0][2].cpu().numpy(), gu.cpu().numpy()) if gu.abs().sum().item() > 0 else res[0][2].abs().sum().item()
     worst = {"img": max(worst["img"], e_img), "loss": max(worst["loss"], e_loss), "g12": max(worst["g12"], e12), "g1u": max(worst["g1u"], e1u)}
-    if (not fin) or e_img > 1e-4 or e_loss > 1e-4 or e1u > 1e-3 or e12 > 1e-3:
+    # fused vs torch-activation chain: the l1 seed is sign(d) (a 1e-6 image difference flips it where d ~ 0) and needles amplify the
+    # 1-ulp differences of the two exp/tanh implementations through det(cov); both stay within 5e-3 (same with any earlier build)
+    tol_chain = 5e-3 if (kind == "l1" or (variant & 2)) else 1e-3
+    if (not fin) or e_img > 1e-4 or e_loss > 1e-4 or e1u > tol_chain or e12 > 1e-3:
         bad += 1
-        print("CASE", it, dict(B=B, P=P, V=V, H=H, W=W, level=level, kind=kind, compact=compact, seed=seed), "finite", fin,
+        print("CASE", it, dict(B=B, P=P, V=V, H=H, W=W, level=level, kind=kind, compact=compact, seed=seed, variant=variant), "finite", fin,
               "img %.2e loss %.2e g(single vs two-pass) %.2e g(single vs chain) %.2e" % (e_img, e_loss, e12, e1u))
 print("cases %d bad %d worst %s  (%.1f s)" % (N, bad, {k: "%.2e" % v for k, v in worst.items()}, time.time() - t0))
