@@ -302,9 +302,9 @@ def main():
                                "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS,
                                "traffic": pmc_traffic(dom, a.config, not (a.unfused or a.compact or a.two_pass)),
                                "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_GB_per_launch"] * 1e9,
-                               "scope": ("one HIP-event scope per launch of render_fb_wave_kernel TOGETHER WITH the bwd_reduce kernel that finishes its "
+                               "scope": ("one HIP-event scope per launch of the tile kernel TOGETHER WITH the bwd_reduce kernel that finishes its "
                                          "gradient accumulation (rocprofv3 lists the two separately: their averages add up to this duration)")
-                                        if dom == "render_fb" else "one HIP-event scope per launch of the kernel"}
+                                        if dom in ("render_fb", "render_bwd") else "one HIP-event scope per launch of the kernel"}
             out["roofline_rasterizer_fwd_bwd"] = {"achieved": (fwd_bytes + bwd_bytes) / 1e9 / (fb_ms / 1e3), "peak": HBM_PEAK_GBS,
                                                   "unit": "GB/s", "frac": (fwd_bytes + bwd_bytes) / 1e9 / (fb_ms / 1e3) / HBM_PEAK_GBS,
                                                   "note": "reference-algorithm bytes fwd (168P+76R+8T+24HW) + bwd (308P+76R+24HW) per view "
