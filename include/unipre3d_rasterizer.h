@@ -45,6 +45,11 @@ extern "C" {
 #define U3D_FLAG_EXACT_AA_GRAD 8 /* exact derivative of the anti-aliasing factor (DEV(vi)) */
 #define U3D_FLAG_STATS 16        /* also accumulate num_rendered[view] = sum of tiles touched (same-address atomics:
                                     ~12 ns each, 0.25 ms at 1.6 M Gaussian-views -- statistics only, off by default) */
+#define U3D_FLAG_ACC_CLEAN 32    /* u3d_render_loss_step only: the caller guarantees that the gradient accumulators at the start of
+                                    `backward_scratch` (the first acc_bytes) are all zero on entry -- because it zeroed them once, or
+                                    because the previous call that used this scratch was a u3d_render_loss_step that returned
+                                    U3D_OK (every such call leaves them zero again).  The step then skips clearing 80 bytes per
+                                    (view, Gaussian) pair, most of its projection kernel's traffic at scene level */
 
 #define U3D_OK 0
 #define U3D_ERR_INVALID_ARGUMENT 1
@@ -173,7 +178,8 @@ int u3d_render_loss_backward(const u3d_raster_desc* desc, const u3d_head_desc* h
  * contributor and the colour image never round-trip through HBM.
  *   out_color   [n_views][3][H][W] or NULL (not needed for training)
  *   loss_out[1] mean loss;  d_head_out [n_items][P][C] = d loss / d head_out  (i.e. for dL/dloss = 1; scale on the host)
- * Scratch: geom, binning, fused and backward_scratch as above (no image buffer).
+ * Scratch: geom, binning, fused and backward_scratch as above (no image buffer).  On return the gradient accumulators in
+ * backward_scratch are zero again (see U3D_FLAG_ACC_CLEAN).
  */
 int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss, const float* bg,
                          const float* head_out, const float* center, const float* viewmatrix, const float* projmatrix,

@@ -308,3 +308,39 @@ def test_more_than_65535_views_in_one_call():
         assert torch.equal(col[0, i], ref[0, i % 4]), i
     # (each Gaussian's gradient is an fp32 sum over its 70 000 views: rounding noise ~1e-4)
     assert rel_l2(xyz.grad.cpu().numpy(), (V // 4) * xyz4.grad.cpu().numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("level,P,V,H,W,faint", [("object", 128, 4, 64, 64, False), ("scene", 700, 3, 48, 80, True), ("scene", 5000, 2, 64, 64, False)])
+def test_single_pass_step_reuses_its_workspace_with_clean_accumulators(level, P, V, H, W, faint):
+    """The single-pass step keeps its backward scratch between calls and tells the library that the gradient accumulators are still
+    zero (U3D_FLAG_ACC_CLEAN: every step re-zeroes what it touched).  Steps on different inputs through the same workspace must be
+    bit-identical to the same steps on a fresh workspace -- including `faint` scenes whose tiles go past the partial-row blocks and
+    add into the accumulators with f64 atomics."""
+    from unipre3d_amd import fused
+    dev = torch.device("cuda:0")
+
+    def step(bd):
+        h = bd.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+        loss, _, _ = fused.render_loss_fused(h, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt, bd.bg, bd.fov_deg, H, W,
+                                             level=level, offset_scale=bd.offset_scale, loss_kind="l2", single_pass=True, return_images=False)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), h.grad.clone()
+
+    batches = []
+    for seed in (3, 4, 5):
+        _, bd = _batch(2, P, V, H, W, level=level, seed=seed)
+        if faint:
+            bd.raw[:, 3] -= 4.0                      # opacity ~ 0.02: no early saturation, every tile walks the whole list
+        batches.append(bd)
+    fresh = []
+    for bd in batches:
+        fused._WS.clear()
+        fresh.append(step(bd))
+        assert any(ws[1] for ws in fused._WS.values())           # the step left its workspace marked clean
+    fused._WS.clear()
+    for rnd in range(2):
+        for bd, (l0, g0) in zip(batches, fresh):
+            l1, g1 = step(bd)                                    # from the second step on: U3D_FLAG_ACC_CLEAN
+            assert torch.equal(l1, l0) and torch.equal(g1, g0), (rnd, float((g1 - g0).abs().max()))
+    assert len(fused._WS) == 1

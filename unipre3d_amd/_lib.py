@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libunipre3d_rasterizer.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-FLAG_PREFILTERED, FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_EXACT_AA_GRAD, FLAG_STATS = 1, 2, 4, 8, 16
+FLAG_PREFILTERED, FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_EXACT_AA_GRAD, FLAG_STATS, FLAG_ACC_CLEAN = 1, 2, 4, 8, 16, 32
 
 EXPORTS = ("u3d_abi_version", "u3d_error_string", "u3d_scratch_query", "u3d_rasterize_forward",
            "u3d_rasterize_backward", "u3d_mark_visible", "u3d_profile_begin", "u3d_profile_end",

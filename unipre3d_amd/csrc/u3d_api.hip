@@ -345,7 +345,8 @@ int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head,
   }
   {
     ProfScope ps(0, s);
-    u3d_launch_preprocess_fwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, s);
+    // (the accumulators are cleared per projected pair here unless the caller vouches for them, U3D_FLAG_ACC_CLEAN)
+    u3d_launch_preprocess_fwd(d, b, src, viewmatrix, projmatrix, campos, radii, (d.flags & U3D_FLAG_ACC_CLEAN) ? nullptr : acc, s);
   }
   if (!u3d_preprocess_sorts(d)) {
     ProfScope ps(1, s);
@@ -363,7 +364,7 @@ int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head,
   sink.shs = d_head_out + 11; sink.colors = nullptr; sink.cov = nullptr; sink.means2D = nullptr; sink.qdot = f.qdot;
   {
     ProfScope ps(4, s);
-    u3d_launch_preprocess_bwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, sink, s);
+    u3d_launch_preprocess_bwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, sink, s, acc);   // reads, then re-zeroes, the touched accumulators
   }
   if (head->mode == 1) u3d_launch_quat_fixup(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, f.qdot, d_head_out + 7, s);
   return finish(desc, s);

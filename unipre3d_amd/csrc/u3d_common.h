@@ -184,7 +184,7 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
                                const float* projmatrix, const float* campos, int32_t* radii, double* acc_zero, hipStream_t s);
 void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, const int32_t* radii, const double* acc,
-                               const U3DGradSink& sink, hipStream_t s);
+                               const U3DGradSink& sink, hipStream_t s, double* acc_reset = nullptr);
 // true when preprocess_fwd also produces the per-view depth order (P <= 256): skip u3d_launch_depth_sort then
 bool u3d_preprocess_sorts(const u3d_raster_desc& d);
 void u3d_launch_quat_norms(int n_items, int P, const float* rots, int s_rots, float* qnorm, float* qdot_zero, hipStream_t s);

@@ -360,7 +360,7 @@ template <int D>
 __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     int P, int vpi, int M, int H, int W, float tanx, float tany, float mod, int flags, size_t NG, U3DSource src,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
-    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const double* __restrict__ acc,
+    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const double* acc, double* acc_reset,
     U3DGradSink sink) {
   // 4 consecutive lanes (a DPP quad) share one Gaussian and split its views: lane&3 = view slot
   __shared__ float s_qdot[4][4];
@@ -445,6 +445,10 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     float a[U3D_NACC];
 #pragma unroll
     for (int k = 0; k < U3D_NACC; ++k) a[k] = live ? (float)acc[(size_t)k * NG + g] : 0.f;
+    if (acc_reset && live) {   // single-pass step: hand the accumulators back zeroed (only touched pairs were ever written)
+#pragma unroll
+      for (int k = 0; k < U3D_NACC; ++k) acc_reset[(size_t)k * NG + g] = 0.0;
+    }
     if (dL_dmeans2D) {
       dL_dmeans2D[g * 3] = a[0]; dL_dmeans2D[g * 3 + 1] = a[1]; dL_dmeans2D[g * 3 + 2] = 0.f;
     }
@@ -776,7 +780,7 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 
 void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, const int32_t* radii, const double* acc,
-                               const U3DGradSink& sink, hipStream_t s) {
+                               const U3DGradSink& sink, hipStream_t s, double* acc_reset) {
   const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
   dim3 grid((d.P + U3D_BLOCK / 4 - 1) / (U3D_BLOCK / 4), d.n_items), block(U3D_BLOCK);
   const int D = src.shs ? d.sh_degree : 0;
@@ -784,7 +788,7 @@ void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 #define LAUNCH(DEG)                                                                                                    \
   hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, d.P, d.views_per_item, d.sh_coeffs, d.image_height, \
                      d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, flags, NG, src, viewmatrix, projmatrix,    \
-                     campos, radii, b.clamped, acc, sink)
+                     campos, radii, b.clamped, acc, acc_reset, sink)
   switch (D) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;

@@ -93,13 +93,20 @@ class _RenderLossStepFn(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         d_head = torch.empty_like(head_out)
         u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
-        geom, binning, fused, scratch = u8(plan.sizes.geom_bytes), u8(plan.sizes.binning_bytes), u8(plan.sizes.fused_bytes), \
-            u8(plan.sizes.backward_bytes)
+        geom, binning, fused = u8(plan.sizes.geom_bytes), u8(plan.sizes.binning_bytes), u8(plan.sizes.fused_bytes)
+        # The backward scratch is kept between steps (per device, stream and size): a step leaves its gradient accumulators zero,
+        # so the next one is told not to clear them again (U3D_FLAG_ACC_CLEAN; 80 bytes per (view, Gaussian) pair at scene level).
+        sp = _stream_ptr(dev)
+        ws = _workspace(dev, sp, plan.sizes.backward_bytes)
+        if ws[1]:
+            plan = _Plan(B, NV // B, P, H, W, tanfov, tanfov, scale_modifier, sh_degree, K, flags | _lib.FLAG_ACC_CLEAN)
+        ws[1] = False                     # (stays false if the call below raises)
         p = _lib.ptr
         rc = lib.u3d_render_loss_step(ctypes.byref(plan.desc), ctypes.byref(hd), ctypes.byref(ld), p(bg), p(head_out), p(center),
                                       p(viewmatrix), p(projmatrix), p(campos), p(gt), p(color), p(radii), p(loss), p(d_head),
-                                      p(geom), p(binning), p(fused), p(scratch), _stream_ptr(dev))
+                                      p(geom), p(binning), p(fused), p(ws[0]), sp)
         _lib.check(rc, "u3d_render_loss_step")
+        ws[1] = True
         ctx.save_for_backward(d_head)
         ctx.set_materialize_grads(False)
         if color is None:
@@ -119,6 +126,17 @@ class _RenderLossStepFn(torch.autograd.Function):
 
 
 _UNIT = {}
+_WS = {}   # (device index, stream, bytes) -> [uint8 tensor, accumulators known to be zero]
+
+
+def _workspace(dev: torch.device, stream, nbytes: int):
+    key = (torch.cuda.current_device(), getattr(stream, "value", stream), int(nbytes))
+    ws = _WS.get(key)
+    if ws is None:
+        if len(_WS) >= 8:                  # shapes come and go (validation sizes, ragged last batch): keep the cache small
+            _WS.pop(next(iter(_WS)))
+        ws = _WS[key] = [torch.empty(int(nbytes), dtype=torch.uint8, device=dev), False]
+    return ws
 
 
 def backward_unit(loss: torch.Tensor) -> None:
