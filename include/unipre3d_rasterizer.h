@@ -47,8 +47,9 @@ extern "C" {
                                     ~12 ns each, 0.25 ms at 1.6 M Gaussian-views -- statistics only, off by default) */
 #define U3D_FLAG_ACC_CLEAN 32    /* u3d_render_loss_step only: the caller guarantees that the gradient accumulators at the start of
                                     `backward_scratch` (the first acc_bytes) are all zero on entry -- because it zeroed them once, or
-                                    because the previous call that used this scratch was a u3d_render_loss_step that returned
-                                    U3D_OK (every such call leaves them zero again).  The step then skips clearing 80 bytes per
+                                    because the previous call that used this scratch was a u3d_render_loss_step WITH THE SAME
+                                    DESCRIPTOR SHAPE that returned U3D_OK (every such call leaves them zero again; another shape
+                                    lays the scratch out differently).  The step then skips clearing 80 bytes per
                                     (view, Gaussian) pair, most of its projection kernel's traffic at scene level */
 
 #define U3D_OK 0

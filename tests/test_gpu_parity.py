@@ -111,6 +111,30 @@ def test_radix_sort_far_depths(oracle_mod, F):
         assert near(g[k].reshape(go[k].shape), go[k], go64[k]), k
 
 
+@pytest.mark.parametrize("n_dense", [800, 3000])
+def test_large_P_sort_dense_depth_bucket(oracle_mod, n_dense):
+    """The large-P sort partitions by the leading depth bits and sorts each bucket in one workgroup: in LDS (<= 1024 keys) or through
+    global ping-pong buffers (more).  A slab of `n_dense` Gaussians at almost the same depth (relative spread 1e-3, with exact
+    ties) lands in one or two buckets and takes the first (800) / second (3000) route."""
+    H, W = 64, 80
+    sc = scene(6000, H, W, seed=12, level="scene", compact=True, deg=1)
+    V = sc["viewmatrix"].double()
+    fwd = V[:3, 2]                                                # d(depth)/d(position)
+    z = torch.cat([sc["means3D"].double(), torch.ones(6000, 1, dtype=torch.float64)], 1) @ V[:, 2]
+    g = torch.Generator().manual_seed(5)
+    target = 2.5 * (1.0 + 1e-3 * torch.rand(n_dense, generator=g, dtype=torch.float64))
+    target[::7] = target[0]                                       # exact ties inside the slab
+    idx = torch.arange(100, 100 + n_dense)
+    sc["means3D"][idx] += ((target - z[idx])[:, None] * fwd[None, :]).float()
+    dcol, dinv = cotangents(H, W)
+    color, invd, radii, gg = _run_gpu(sc, dcol, dinv)
+    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
+    assert np.array_equal(radii, r.radii) and near(color, r.color, r64.color)
+    go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
+    for k in DIFF_KEYS:
+        assert near(gg[k].reshape(go[k].shape), go[k], go64[k]), k
+
+
 def test_depth_ties_small_P(oracle_mod):
     sc = scene(200, 64, 96, seed=4, compact=True)
     sc["means3D"][10:40] = sc["means3D"][10]

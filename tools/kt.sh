@@ -10,7 +10,7 @@ import csv, sys, re
 out = []
 for r in csv.DictReader(open(sys.argv[1])):
     m = re.search(r"(\w+_kernel)", r["Name"])
-    if m and m.group(1) in ("render_fb_wave_kernel", "bwd_reduce_kernel", "bwd_reduce1_kernel", "preprocess_fwd_kernel", "preprocess_bwd_kernel", "quat_norms_kernel", "quat_fixup_kernel", "render_fwd_wave_kernel", "render_bwd_wave_kernel", "radix_hist_kernel", "radix_scatter_kernel", "depth_sort_block_radix_kernel"):
+    if m and m.group(1) in ("render_fb_wave_kernel", "bwd_reduce_kernel", "bwd_reduce1_kernel", "preprocess_fwd_kernel", "preprocess_bwd_kernel", "quat_norms_kernel", "quat_fixup_kernel", "render_fwd_wave_kernel", "render_bwd_wave_kernel", "radix_hist_kernel", "radix_scatter_kernel", "depth_sort_block_radix_kernel", "msd_hist_kernel", "msd_scatter_kernel", "bucket_sort_kernel"):
         out.append("%s %.1f(x%s)" % (m.group(1).replace("_kernel", ""), float(r["AverageNs"]) / 1e3, r["Calls"]))
 print(sys.argv[2], " ".join(out))
 PY

@@ -43,7 +43,8 @@ struct U3DBuffers {
   uint32_t* n_vis;       // [NV]   number of entries of the sorted list that are on screen
   uint32_t* sort_keys[2];  // [NV*P] x2  radix ping-pong (large P only)
   uint32_t* sort_vals[2];  // [NV*P] x2
-  uint32_t* sort_hist;     // radix histograms
+  uint32_t* sort_hist;     // per-block bucket histograms [NV][blocks][512]
+  uint32_t* sort_over;     // bucket start table [NV][513]
   // image
   float* final_T;        // [NV*H*W]
   uint32_t* n_contrib;   // [NV*H*W]  exclusive sorted-position limit of the pixel (position at which it saturated, else UINT_MAX)
@@ -154,9 +155,10 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
     CARVE(bn, sort_vals[0], uint32_t, NG);
     CARVE(bn, sort_vals[1], uint32_t, NG);
     const size_t nblk = ((size_t)d.P + u3d_radix_tile(d.P) - 1) / u3d_radix_tile(d.P);
-    CARVE(bn, sort_hist, uint32_t, NV * 256 * nblk);
+    CARVE(bn, sort_hist, uint32_t, NV * 512 * nblk);
+    CARVE(bn, sort_over, uint32_t, NV * 513);
   } else if (b) {
-    b->sort_keys[0] = b->sort_keys[1] = b->sort_vals[0] = b->sort_vals[1] = b->sort_hist = nullptr;
+    b->sort_keys[0] = b->sort_keys[1] = b->sort_vals[0] = b->sort_vals[1] = b->sort_hist = b->sort_over = nullptr;
   }
   L.binning_bytes = o > 0 ? o : 256;
   o = 0;

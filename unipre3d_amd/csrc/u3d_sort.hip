@@ -9,11 +9,8 @@
 //
 //  * P <= 256: fused into preprocess_fwd (bitonic network over 256 (depth bits << 32 | index) keys in LDS).
 //  * P <= 4096: one workgroup per view, 4-pass LSD radix sort entirely in LDS (64 KiB of the CU's 160 KiB), one launch.
-//  * larger P: 4-pass LSD radix sort (8-bit digits) on the depth bits with the index as payload;
-//    LSD passes are stable and the initial order is index order, so ties resolve by index.  Per pass: per-block digit
-//    histogram, then a scatter whose prologue turns the histograms into its own offsets (no separate scan launch) and
-//    ranks keys with ballot multi-split (8 ballots per key, stable within the wave, waves ordered through LDS); the last
-//    pass writes the sorted ids and their tile rectangles directly.
+//  * larger P: one most-significant-digit partition into 512 depth buckets (histogram + stable scatter), then one workgroup per
+//    bucket sorts it in LDS and writes the sorted ids and tile rectangles: three launches (see below).
 #include "u3d_common.h"
 
 namespace {
@@ -120,82 +117,153 @@ __global__ __launch_bounds__(NT) void depth_sort_block_radix_kernel(int P, int N
   }
 }
 
-// ---- large P: LSD radix sort, 8-bit digits, ITEMS*256 keys per workgroup (u3d_radix_tile) -------
+// ---- large P: one most-significant-digit partition, then every bucket sorted by its own workgroup -------------------------
+// Key = depth bits - bits(0.2f): a visible Gaussian has depth > 0.2 (the near cull), so the difference is >= 1 and order-preserving.
+// Bucket = min(key >> 18, 511): 32 buckets per octave of depth up to 13107.2, everything beyond in the last one.
+//   msd_hist     per-block bucket histogram (culled Gaussians are dropped here: they are neither counted nor moved);
+//   msd_scatter  stable partition into bucket order (ballot multi-split ranking, per-block offsets from the histograms), bucket
+//                start table, n_vis;
+//   bucket_sort  one 256-thread workgroup per (view, bucket): LSD radix sort of the bucket's keys on their low 24 bits (the
+//                whole key in the last bucket), in LDS when the bucket fits (<= 1024 keys), through the global ping-pong buffers
+//                otherwise (an unusually dense or degenerate bucket: correct, slower); writes the sorted ids and rectangles.
+// Three launches instead of the nine of a four-pass LSD sort over all keys (each of which is latency-bound at these sizes).
+// Stable throughout and the initial order is index order, so depth ties resolve by ascending Gaussian index.
+constexpr uint32_t MSD_KEY_BASE = 0x3E4CCCCDu;   // bits of 0.2f
+constexpr int MSD_SHIFT = 18, MSD_BITS = 9, MSD_BINS = 1 << MSD_BITS;
+constexpr int BUCKET_NT = 256, BUCKET_LDS_CAP = 1024;   // (LDS per workgroup decides how many buckets a CU sorts at once: 1024 measured best)
 
-__device__ __forceinline__ uint32_t radix_key(int pass, int P, int idx, size_t base, const float* depth,
-                                              const int32_t* radii, const uint32_t* keys_in) {
-  if (pass == 0) return radii[base + idx] > 0 ? __float_as_uint(depth[base + idx]) : 0xFFFFFFFFu;
-  return keys_in[base + idx];
+__device__ __forceinline__ uint32_t msd_key(int P, int idx, size_t base, const float* depth, const int32_t* radii) {
+  return radii[base + idx] > 0 ? __float_as_uint(depth[base + idx]) - MSD_KEY_BASE : 0xFFFFFFFFu;
 }
+__device__ __forceinline__ uint32_t msd_bucket(uint32_t k) { return min(k >> MSD_SHIFT, (uint32_t)(MSD_BINS - 1)); }
 
-// Pass 0 drops the culled Gaussians (key 0xFFFFFFFF): they are neither counted nor scattered, so passes 1-3 and the
-// finalize step only see the n_vis[view] visible keys (53 % of the keys at C5); workgroups past that count leave at once.
-// NT threads x ITEMS keys per workgroup and pass.
 template <int NT, int ITEMS>
-__global__ __launch_bounds__(NT) void radix_hist_kernel(int pass, int P, int nblk, const float* __restrict__ depth,
-                                                        const int32_t* __restrict__ radii, const uint32_t* __restrict__ keys_in,
-                                                        const uint32_t* __restrict__ n_vis, uint32_t* __restrict__ hist) {
-  __shared__ uint32_t h[256];
+__global__ __launch_bounds__(NT) void msd_hist_kernel(int P, int nblk, const float* __restrict__ depth, const int32_t* __restrict__ radii,
+                                                      uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[MSD_BINS];
   const int view = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)view * P;
-  const int limit = pass == 0 ? P : (int)n_vis[view];
-  if (tid < 256) h[tid] = 0;
+  if (tid < MSD_BINS) h[tid] = 0;
   __syncthreads();
-  if (blk * (ITEMS * NT) < limit) {
 #pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-      const int idx = blk * (ITEMS * NT) + r * NT + tid;
-      if (idx < limit) {
-        const uint32_t k = radix_key(pass, P, idx, base, depth, radii, keys_in);
-        if (k != 0xFFFFFFFFu) atomicAdd(&h[(k >> (8 * pass)) & 255u], 1u);
-      }
+  for (int r = 0; r < ITEMS; ++r) {
+    const int idx = blk * (ITEMS * NT) + r * NT + tid;
+    if (idx < P) {
+      const uint32_t k = msd_key(P, idx, base, depth, radii);
+      if (k != 0xFFFFFFFFu) atomicAdd(&h[msd_bucket(k)], 1u);
     }
-    __syncthreads();
   }
-  if (tid < 256) hist[((size_t)view * nblk + blk) * 256 + tid] = h[tid];   // [view][block][digit]: coalesced
+  __syncthreads();
+  if (tid < MSD_BINS) hist[((size_t)view * nblk + blk) * MSD_BINS + tid] = h[tid];   // [view][block][bucket]: coalesced
 }
 
 template <int NT, int ITEMS>
-__global__ __launch_bounds__(NT) void radix_scatter_kernel(int pass, int P, int nblk, const float* __restrict__ depth,
-                                                           const int32_t* __restrict__ radii, const uint32_t* __restrict__ keys_in,
-                                                           const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
-                                                           uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ hist,
-                                                           uint32_t* __restrict__ n_vis, const uint2* __restrict__ rect,
-                                                           uint32_t* __restrict__ sorted_id, uint2* __restrict__ sorted_rect) {
+__global__ __launch_bounds__(NT) void msd_scatter_kernel(int P, int nblk, const float* __restrict__ depth, const int32_t* __restrict__ radii,
+                                                         uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                         const uint32_t* __restrict__ hist, uint32_t* __restrict__ n_vis,
+                                                         uint32_t* __restrict__ bucket_off) {
   constexpr int NW = NT / 64;
-  __shared__ uint32_t digit_base[256];
-  __shared__ uint32_t wave_cnt[2][NW][256];   // double-buffered per round: counts, then exclusive prefixes over the waves
-  __shared__ uint32_t wave_tot[4];
+  static_assert(NT >= MSD_BINS, "one thread per bucket in the prologue");
+  extern __shared__ uint32_t s_dyn[];                                   // wave_cnt[2][NW][MSD_BINS], double-buffered per round:
+  uint32_t (*wave_cnt)[NW][MSD_BINS] = reinterpret_cast<uint32_t (*)[NW][MSD_BINS]>(s_dyn);   // counts, then prefixes over the waves
+  __shared__ uint32_t digit_base[MSD_BINS];
+  __shared__ uint32_t wave_tot[MSD_BINS / 64];
   const int view = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6;
   const uint32_t lane = u3d_lane_id();
   const size_t base = (size_t)view * P;
-  const int limit = pass == 0 ? P : (int)n_vis[view];
-  if (pass == 3) {
-    // the last pass writes the sorted list itself (ids and their tile rectangles; no separate gather launch); positions past the
-    // visible keys read id 0 / empty rectangle
-    for (int idx = blk * (ITEMS * NT) + tid; idx < min(P, (blk + 1) * (ITEMS * NT)); idx += NT)
-      if (idx >= limit) { sorted_id[base + idx] = 0u; sorted_rect[base + idx] = make_uint2(0u, 0u); }
-  }
-  if (blk * (ITEMS * NT) >= limit) return;   // whole workgroup past the visible keys (uniform)
-  for (int e = tid; e < 2 * NW * 256; e += NT) (&wave_cnt[0][0][0])[e] = 0;
+  for (int e = tid; e < 2 * NW * MSD_BINS; e += NT) (&wave_cnt[0][0][0])[e] = 0;
   {
-    // global offset of (digit tid, this block) in digit-major / block-minor order, from the per-block counts
-    // hist[view][b][digit] (every block redoes this small scan: no separate scan launch between histogram and scatter;
-    // 8 loads in flight: the column walk is latency-bound and was most of this kernel's time)
+    // global offset of (bucket tid, this block) in bucket-major / block-minor order, from the per-block counts hist[view][b][bucket]
+    // (every block redoes this small scan: no separate scan launch; 8 loads in flight: the column walk is latency-bound)
     uint32_t tot = 0, before = 0, inc = 0;
-    if (tid < 256) {
-      const uint32_t* col = hist + (size_t)view * nblk * 256 + tid;
+    if (tid < MSD_BINS) {
+      const uint32_t* col = hist + (size_t)view * nblk * MSD_BINS + tid;
       int b = 0;
       for (; b + 7 < nblk; b += 8) {
         uint32_t c[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] = col[(size_t)(b + u) * 256];
+        for (int u = 0; u < 8; ++u) c[u] = col[(size_t)(b + u) * MSD_BINS];
 #pragma unroll
         for (int u = 0; u < 8; ++u) { tot += c[u]; before += b + u < blk ? c[u] : 0u; }
       }
-      for (; b < nblk; ++b) { const uint32_t c0 = col[(size_t)b * 256]; tot += c0; before += b < blk ? c0 : 0u; }
-      inc = tot;   // inclusive scan of the 256 digit totals: shuffles inside each of the four waves, then the wave totals
+      for (; b < nblk; ++b) { const uint32_t c0 = col[(size_t)b * MSD_BINS]; tot += c0; before += b < blk ? c0 : 0u; }
+      inc = tot;   // inclusive scan of the bucket totals: shuffles inside each of the first waves, then the wave totals
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
+        if ((int)lane >= o) inc += v;
+      }
+      if (lane == 63) wave_tot[wave] = inc;
+    }
+    __syncthreads();
+    if (tid < MSD_BINS) {
+      uint32_t off = 0;
+      for (int w = 0; w < wave; ++w) off += wave_tot[w];
+      const uint32_t start = off + inc - tot;
+      if (blk == 0) {
+        bucket_off[(size_t)view * (MSD_BINS + 1) + tid] = start;
+        if (tid == MSD_BINS - 1) { bucket_off[(size_t)view * (MSD_BINS + 1) + MSD_BINS] = off + inc; n_vis[view] = off + inc; }
+      }
+      digit_base[tid] = start + before;
+    }
+    __syncthreads();
+  }
+  for (int r = 0; r < ITEMS; ++r) {
+    const int idx = blk * (ITEMS * NT) + r * NT + tid;
+    bool valid = idx < P;
+    uint32_t k = 0, digit = 0;
+    if (valid) {
+      k = msd_key(P, idx, base, depth, radii);
+      digit = msd_bucket(k);
+      valid = k != 0xFFFFFFFFu;
+    }
+    // lanes of this wave holding the same bucket (stable multi-split, one ballot per bit)
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < MSD_BITS; ++b) {
+      const bool bit = (digit >> b) & 1u;
+      const unsigned long long m = __ballot(bit && valid);
+      same &= bit ? m : ~m;
+    }
+    const uint32_t rank = __popcll(same & ((1ull << lane) - 1ull));
+    uint32_t (*cnt)[MSD_BINS] = wave_cnt[r & 1];
+    if (valid && rank == 0) cnt[wave][digit] = (uint32_t)__popcll(same);
+    __syncthreads();
+    if (tid < MSD_BINS) {   // counts -> destination of each wave's first key of this bucket; digit_base moves past the round
+      uint32_t run = digit_base[tid];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = run; run += c; }
+      digit_base[tid] = run;
+    }
+    __syncthreads();
+    if (valid) {
+      const uint32_t dst = cnt[wave][digit] + rank;
+      keys_out[base + dst] = k;
+      vals_out[base + dst] = (uint32_t)idx;
+    }
+    for (int e = tid; e < NW * MSD_BINS; e += NT) (&wave_cnt[(r + 1) & 1][0][0])[e] = 0;   // the other buffer, for the next round
+    __syncthreads();
+  }
+}
+
+// One stable 8-bit LSD pass of a workgroup over n keys (kin/vin -> kout/vout; LDS or global arrays), digit = (key >> sh) & 255.
+template <int NT>
+__device__ __forceinline__ void wg_radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int n, int sh,
+                                              uint32_t* digit_base, uint32_t (*wave_cnt)[NT / 64][256], uint32_t* wave_tot) {
+  constexpr int NW = NT / 64;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const uint32_t lane = u3d_lane_id();
+  if (tid < 256) digit_base[tid] = 0;
+  for (int e = tid; e < 2 * NW * 256; e += NT) (&wave_cnt[0][0][0])[e] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += NT) atomicAdd(&digit_base[(kin[i] >> sh) & 255u], 1u);
+  __syncthreads();
+  {   // exclusive scan of the 256 totals (NT = 256: all four waves): inclusive scan inside each wave, then the wave totals
+    uint32_t tot = 0, inc = 0;
+    if (tid < 256) {
+      tot = digit_base[tid];
+      inc = tot;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
@@ -207,22 +275,16 @@ __global__ __launch_bounds__(NT) void radix_scatter_kernel(int pass, int P, int 
     if (tid < 256) {
       uint32_t off = 0;
       for (int w = 0; w < wave; ++w) off += wave_tot[w];
-      if (pass == 0 && blk == 0 && tid == 255) n_vis[view] = off + inc;   // total of the visible keys of this view
-      digit_base[tid] = off + inc - tot + before;
+      digit_base[tid] = off + inc - tot;
     }
     __syncthreads();
   }
-  for (int r = 0; r < ITEMS; ++r) {
-    const int idx = blk * (ITEMS * NT) + r * NT + tid;
-    bool valid = idx < limit;
-    uint32_t k = 0, v = 0, digit = 0;
-    if (valid) {
-      k = radix_key(pass, P, idx, base, depth, radii, keys_in);
-      v = pass == 0 ? (uint32_t)idx : vals_in[base + idx];
-      digit = (k >> (8 * pass)) & 255u;
-      valid = k != 0xFFFFFFFFu;          // (only pass 0 meets culled entries)
-    }
-    // lanes of this wave holding the same digit (stable multi-split via 8 ballots)
+  const int rounds = (n + NT - 1) / NT;
+  for (int r = 0; r < rounds; ++r) {
+    const int idx = r * NT + tid;
+    const bool valid = idx < n;
+    const uint32_t k = valid ? kin[idx] : 0u, v = valid ? vin[idx] : 0u;
+    const uint32_t digit = (k >> sh) & 255u;
     unsigned long long same = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -234,7 +296,7 @@ __global__ __launch_bounds__(NT) void radix_scatter_kernel(int pass, int P, int 
     uint32_t (*cnt)[256] = wave_cnt[r & 1];
     if (valid && rank == 0) cnt[wave][digit] = (uint32_t)__popcll(same);
     __syncthreads();
-    if (tid < 256) {   // counts -> destination of each wave's first key of this digit; digit_base moves past the round
+    if (tid < 256) {
       uint32_t run = digit_base[tid];
 #pragma unroll
       for (int w = 0; w < NW; ++w) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = run; run += c; }
@@ -243,16 +305,62 @@ __global__ __launch_bounds__(NT) void radix_scatter_kernel(int pass, int P, int 
     __syncthreads();
     if (valid) {
       const uint32_t dst = cnt[wave][digit] + rank;
-      if (pass == 3) {
-        sorted_id[base + dst] = v;
-        sorted_rect[base + dst] = rect[base + v];
-      } else {
-        keys_out[base + dst] = k;
-        vals_out[base + dst] = v;
-      }
+      kout[dst] = k;
+      vout[dst] = v;
     }
-    for (int e = tid; e < NW * 256; e += NT) (&wave_cnt[(r + 1) & 1][0][0])[e] = 0;   // the other buffer, for the next round
+    for (int e = tid; e < NW * 256; e += NT) (&wave_cnt[(r + 1) & 1][0][0])[e] = 0;
+    __threadfence_block();   // (global ping-pong: this pass's stores are read by other threads of the workgroup in the next one)
     __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(BUCKET_NT) void bucket_sort_kernel(int P, int lds_cap, uint32_t* __restrict__ keys0, uint32_t* __restrict__ vals0,
+                                                                uint32_t* __restrict__ keys1, uint32_t* __restrict__ vals1,
+                                                                const uint32_t* __restrict__ bucket_off, const uint2* __restrict__ rect,
+                                                                uint32_t* __restrict__ sorted_id, uint2* __restrict__ sorted_rect) {
+  constexpr int NT = BUCKET_NT, NW = NT / 64;
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_data[];   // keys[2][cap], vals[2][cap]
+  __shared__ uint32_t digit_base[256];
+  __shared__ uint32_t wave_cnt[2][NW][256];
+  __shared__ uint32_t wave_tot[4];
+  const int view = blockIdx.y, bucket = blockIdx.x, tid = threadIdx.x;
+  const size_t base = (size_t)view * P;
+  const uint32_t start = bucket_off[(size_t)view * (MSD_BINS + 1) + bucket], end = bucket_off[(size_t)view * (MSD_BINS + 1) + bucket + 1];
+  const int n = (int)(end - start);
+  if (n == 0) {
+    // (positions past the visible keys read id 0 / empty rectangle: the last bucket's workgroup fills them)
+  } else if (n == 1) {
+    if (tid == 0) { const uint32_t v = vals0[base + start]; sorted_id[base + start] = v; sorted_rect[base + start] = rect[base + v]; }
+  } else {
+    // bits that can differ inside a bucket: the low 18 (sorted as three 8-bit digits), the whole key in the last bucket
+    const int passes = bucket == MSD_BINS - 1 ? 4 : 3;
+    const uint32_t* kf;
+    const uint32_t* vf;
+    if (n <= lds_cap) {
+      uint32_t* lk[2] = {s_data, s_data + lds_cap};
+      uint32_t* lv[2] = {s_data + 2 * lds_cap, s_data + 3 * lds_cap};
+      for (int i = tid; i < n; i += NT) { lk[0][i] = keys0[base + start + i]; lv[0][i] = vals0[base + start + i]; }
+      __syncthreads();
+      for (int p = 0; p < passes; ++p)
+        wg_radix_pass<NT>(lk[p & 1], lv[p & 1], lk[(p + 1) & 1], lv[(p + 1) & 1], n, 8 * p, digit_base, wave_cnt, wave_tot);
+      kf = lk[passes & 1]; vf = lv[passes & 1];
+    } else {
+      uint32_t* gk[2] = {keys0 + base + start, keys1 + base + start};
+      uint32_t* gv[2] = {vals0 + base + start, vals1 + base + start};
+      for (int p = 0; p < passes; ++p)
+        wg_radix_pass<NT>(gk[p & 1], gv[p & 1], gk[(p + 1) & 1], gv[(p + 1) & 1], n, 8 * p, digit_base, wave_cnt, wave_tot);
+      kf = gk[passes & 1]; vf = gv[passes & 1];
+    }
+    (void)kf;
+    for (int i = tid; i < n; i += NT) {
+      const uint32_t v = vf[i];
+      sorted_id[base + start + i] = v;
+      sorted_rect[base + start + i] = rect[base + v];
+    }
+  }
+  if (bucket == MSD_BINS - 1) {
+    const uint32_t nv = bucket_off[(size_t)view * (MSD_BINS + 1) + MSD_BINS];
+    for (int i = (int)nv + tid; i < P; i += NT) { sorted_id[base + i] = 0u; sorted_rect[base + i] = make_uint2(0u, 0u); }
   }
 }
 
@@ -282,19 +390,25 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
   }
   const int tile = u3d_radix_tile(d.P);
   const int nblk = (d.P + tile - 1) / tile;
-  for (int pass = 0; pass < 4; ++pass) {
-    const uint32_t* kin = pass == 0 ? nullptr : b.sort_keys[(pass + 1) & 1];
-    const uint32_t* vin = pass == 0 ? nullptr : b.sort_vals[(pass + 1) & 1];
-    uint32_t* kout = b.sort_keys[pass & 1];
-    uint32_t* vout = b.sort_vals[pass & 1];
+  static const int lds_cap = getenv("U3D_BUCKET_LDS_CAP") ? atoi(getenv("U3D_BUCKET_LDS_CAP")) : BUCKET_LDS_CAP;   // (tests force the global path)
 #define LAUNCH(NT, IT)                                                                                                       \
   do {                                                                                                                       \
-    hipLaunchKernelGGL((radix_hist_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), 0, s, pass, d.P, nblk, b.depth, radii, kin,    \
-                       b.n_vis, b.sort_hist);                                                                                \
-    hipLaunchKernelGGL((radix_scatter_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), 0, s, pass, d.P, nblk, b.depth, radii, kin, \
-                       vin, kout, vout, b.sort_hist, b.n_vis, b.rect, b.sorted_id, b.sorted_rect);                           \
+    constexpr size_t lds = (size_t)2 * (NT / 64) * MSD_BINS * sizeof(uint32_t);                                              \
+    static bool attr = false;                                                                                                \
+    if (!attr) {                                                                                                             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_scatter_kernel<NT, IT>),                                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                4 * 4096 * (int)sizeof(uint32_t));                                                          \
+      attr = true;                                                                                                           \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((msd_hist_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), 0, s, d.P, nblk, b.depth, radii, b.sort_hist);   \
+    hipLaunchKernelGGL((msd_scatter_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), lds, s, d.P, nblk, b.depth, radii,            \
+                       b.sort_keys[0], b.sort_vals[0], b.sort_hist, b.n_vis, b.sort_over);                                   \
   } while (0)
-    if (d.P <= 65536) LAUNCH(U3D_RADIX_NT_SMALL, U3D_RADIX_IT_SMALL); else LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE);
+  if (d.P <= 65536) LAUNCH(U3D_RADIX_NT_SMALL, U3D_RADIX_IT_SMALL); else LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE);
 #undef LAUNCH
-  }
+  const int cap = lds_cap < 1 ? 1 : (lds_cap > 4096 ? 4096 : lds_cap);
+  hipLaunchKernelGGL(bucket_sort_kernel, dim3(MSD_BINS, NV), dim3(BUCKET_NT), (size_t)4 * cap * sizeof(uint32_t), s, d.P, cap,
+                     b.sort_keys[0], b.sort_vals[0], b.sort_keys[1], b.sort_vals[1], b.sort_over, b.rect, b.sorted_id, b.sorted_rect);
 }

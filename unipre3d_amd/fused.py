@@ -97,7 +97,7 @@ class _RenderLossStepFn(torch.autograd.Function):
         # The backward scratch is kept between steps (per device, stream and size): a step leaves its gradient accumulators zero,
         # so the next one is told not to clear them again (U3D_FLAG_ACC_CLEAN; 80 bytes per (view, Gaussian) pair at scene level).
         sp = _stream_ptr(dev)
-        ws = _workspace(dev, sp, plan.sizes.backward_bytes)
+        ws = _workspace(dev, sp, plan.sizes.backward_bytes, (B, NV // B, P, H, W, K))
         if ws[1]:
             plan = _Plan(B, NV // B, P, H, W, tanfov, tanfov, scale_modifier, sh_degree, K, flags | _lib.FLAG_ACC_CLEAN)
         ws[1] = False                     # (stays false if the call below raises)
@@ -126,11 +126,13 @@ class _RenderLossStepFn(torch.autograd.Function):
 
 
 _UNIT = {}
-_WS = {}   # (device index, stream, bytes) -> [uint8 tensor, accumulators known to be zero]
+_WS = {}   # (device index, stream, bytes, call shape) -> [uint8 tensor, accumulators known to be zero]
 
 
-def _workspace(dev: torch.device, stream, nbytes: int):
-    key = (torch.cuda.current_device(), getattr(stream, "value", stream), int(nbytes))
+def _workspace(dev: torch.device, stream, nbytes: int, shape):
+    # keyed by the call shape, not by the size: "accumulators are zero" is a statement about one scratch LAYOUT (another shape of
+    # the same total size puts its accumulators where this one keeps partial rows)
+    key = (torch.cuda.current_device(), getattr(stream, "value", stream), int(nbytes)) + tuple(shape)
     ws = _WS.get(key)
     if ws is None:
         if len(_WS) >= 8:                  # shapes come and go (validation sizes, ragged last batch): keep the cache small
