@@ -123,14 +123,14 @@ __global__ __launch_bounds__(NT) void depth_sort_block_radix_kernel(int P, int N
 //   msd_hist     per-block bucket histogram (culled Gaussians are dropped here: they are neither counted nor moved);
 //   msd_scatter  stable partition into bucket order (ballot multi-split ranking, per-block offsets from the histograms), bucket
 //                start table, n_vis;
-//   bucket_sort  one 256-thread workgroup per (view, bucket): LSD radix sort of the bucket's keys on their low 24 bits (the
+//   bucket_sort  one 256- or 512-thread workgroup per (view, bucket): LSD radix sort of the bucket's keys on their low 24 bits (the
 //                whole key in the last bucket), in LDS when the bucket fits (<= 1024 keys), through the global ping-pong buffers
 //                otherwise (an unusually dense or degenerate bucket: correct, slower); writes the sorted ids and rectangles.
 // Three launches instead of the nine of a four-pass LSD sort over all keys (each of which is latency-bound at these sizes).
 // Stable throughout and the initial order is index order, so depth ties resolve by ascending Gaussian index.
 constexpr uint32_t MSD_KEY_BASE = 0x3E4CCCCDu;   // bits of 0.2f
 constexpr int MSD_SHIFT = 18, MSD_BITS = 9, MSD_BINS = 1 << MSD_BITS;
-constexpr int BUCKET_NT = 256, BUCKET_LDS_CAP = 1024;   // (LDS per workgroup decides how many buckets a CU sorts at once: 1024 measured best)
+constexpr int BUCKET_LDS_CAP = 1024;   // (LDS per workgroup decides how many buckets a CU sorts at once: 1024 measured best)
 
 __device__ __forceinline__ uint32_t msd_key(int P, int idx, size_t base, const float* depth, const int32_t* radii) {
   return radii[base + idx] > 0 ? __float_as_uint(depth[base + idx]) - MSD_KEY_BASE : 0xFFFFFFFFu;
@@ -314,6 +314,7 @@ __device__ __forceinline__ void wg_radix_pass(const uint32_t* kin, const uint32_
   }
 }
 
+template <int BUCKET_NT>   // 256 threads per bucket up to 64 k Gaussians per view, 512 beyond (denser buckets: C5 sort 97 -> 85 us, C4 49 -> 52)
 __global__ __launch_bounds__(BUCKET_NT) void bucket_sort_kernel(int P, int lds_cap, uint32_t* __restrict__ keys0, uint32_t* __restrict__ vals0,
                                                                 uint32_t* __restrict__ keys1, uint32_t* __restrict__ vals1,
                                                                 const uint32_t* __restrict__ bucket_off, const uint2* __restrict__ rect,
@@ -398,7 +399,9 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
     if (!attr) {                                                                                                             \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_scatter_kernel<NT, IT>),                                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sort_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                4 * 4096 * (int)sizeof(uint32_t));                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sort_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 4 * 4096 * (int)sizeof(uint32_t));                                                          \
       attr = true;                                                                                                           \
     }                                                                                                                        \
@@ -409,6 +412,10 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
   if (d.P <= 65536) LAUNCH(U3D_RADIX_NT_SMALL, U3D_RADIX_IT_SMALL); else LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE);
 #undef LAUNCH
   const int cap = lds_cap < 1 ? 1 : (lds_cap > 4096 ? 4096 : lds_cap);
-  hipLaunchKernelGGL(bucket_sort_kernel, dim3(MSD_BINS, NV), dim3(BUCKET_NT), (size_t)4 * cap * sizeof(uint32_t), s, d.P, cap,
-                     b.sort_keys[0], b.sort_vals[0], b.sort_keys[1], b.sort_vals[1], b.sort_over, b.rect, b.sorted_id, b.sorted_rect);
+  if (d.P <= 65536)
+    hipLaunchKernelGGL(bucket_sort_kernel<256>, dim3(MSD_BINS, NV), dim3(256), (size_t)4 * cap * sizeof(uint32_t), s, d.P, cap, b.sort_keys[0],
+                       b.sort_vals[0], b.sort_keys[1], b.sort_vals[1], b.sort_over, b.rect, b.sorted_id, b.sorted_rect);
+  else
+    hipLaunchKernelGGL(bucket_sort_kernel<512>, dim3(MSD_BINS, NV), dim3(512), (size_t)4 * cap * sizeof(uint32_t), s, d.P, cap, b.sort_keys[0],
+                       b.sort_vals[0], b.sort_keys[1], b.sort_vals[1], b.sort_over, b.rect, b.sorted_id, b.sorted_rect);
 }
