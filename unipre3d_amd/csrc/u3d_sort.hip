@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NT) void depth_sort_block_radix_kernel(int P, int N
 //   msd_hist     per-block bucket histogram (culled Gaussians are dropped here: they are neither counted nor moved);
 //   msd_scatter  stable partition into bucket order (ballot multi-split ranking, per-block offsets from the histograms), bucket
 //                start table, n_vis;
-//   bucket_sort  one 256- or 512-thread workgroup per (view, bucket): LSD radix sort of the bucket's keys on their low 24 bits (the
+//   bucket_sort  one 256- or 512-thread workgroup per (view, bucket): LSD radix sort (6-bit digits) of the bucket's keys on their low 18 bits (the
 //                whole key in the last bucket), in LDS when the bucket fits (<= 1024 keys), through the global ping-pong buffers
 //                otherwise (an unusually dense or degenerate bucket: correct, slower); writes the sorted ids and rectangles.
 // Three launches instead of the nine of a four-pass LSD sort over all keys (each of which is latency-bound at these sizes).
@@ -247,56 +247,50 @@ __global__ __launch_bounds__(NT) void msd_scatter_kernel(int P, int nblk, const 
   }
 }
 
-// One stable 8-bit LSD pass of a workgroup over n keys (kin/vin -> kout/vout; LDS or global arrays), digit = (key >> sh) & 255.
-template <int NT>
+// One stable LSD pass of a workgroup over n keys (kin/vin -> kout/vout; LDS or global arrays), digit = (key >> sh) & (2^BITS - 1).
+// 6-bit digits: the 64 digit totals are scanned by one wave and the per-wave count table is 4x smaller than with 8 bits -- the fixed
+// cost of a pass matters more than the pass count for buckets of a few hundred keys.
+template <int NT, int BITS>
 __device__ __forceinline__ void wg_radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int n, int sh,
-                                              uint32_t* digit_base, uint32_t (*wave_cnt)[NT / 64][256], uint32_t* wave_tot) {
-  constexpr int NW = NT / 64;
+                                              uint32_t* digit_base, uint32_t (*wave_cnt)[NT / 64][1 << BITS]) {
+  constexpr int NW = NT / 64, BINS = 1 << BITS;
+  static_assert(BINS == 64, "the digit totals are scanned by one wave");
   const int tid = threadIdx.x, wave = tid >> 6;
   const uint32_t lane = u3d_lane_id();
-  if (tid < 256) digit_base[tid] = 0;
-  for (int e = tid; e < 2 * NW * 256; e += NT) (&wave_cnt[0][0][0])[e] = 0;
+  if (tid < BINS) digit_base[tid] = 0;
+  for (int e = tid; e < 2 * NW * BINS; e += NT) (&wave_cnt[0][0][0])[e] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += NT) atomicAdd(&digit_base[(kin[i] >> sh) & 255u], 1u);
+  for (int i = tid; i < n; i += NT) atomicAdd(&digit_base[(kin[i] >> sh) & (BINS - 1)], 1u);
   __syncthreads();
-  {   // exclusive scan of the 256 totals (NT = 256: all four waves): inclusive scan inside each wave, then the wave totals
-    uint32_t tot = 0, inc = 0;
-    if (tid < 256) {
-      tot = digit_base[tid];
-      inc = tot;
+  if (tid < BINS) {   // exclusive scan of the 64 totals inside the first wave
+    const uint32_t tot = digit_base[tid];
+    uint32_t inc = tot;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
-        if ((int)lane >= o) inc += v;
-      }
-      if (lane == 63) wave_tot[wave] = inc;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
+      if ((int)lane >= o) inc += v;
     }
-    __syncthreads();
-    if (tid < 256) {
-      uint32_t off = 0;
-      for (int w = 0; w < wave; ++w) off += wave_tot[w];
-      digit_base[tid] = off + inc - tot;
-    }
-    __syncthreads();
+    digit_base[tid] = inc - tot;
   }
+  __syncthreads();
   const int rounds = (n + NT - 1) / NT;
   for (int r = 0; r < rounds; ++r) {
     const int idx = r * NT + tid;
     const bool valid = idx < n;
     const uint32_t k = valid ? kin[idx] : 0u, v = valid ? vin[idx] : 0u;
-    const uint32_t digit = (k >> sh) & 255u;
+    const uint32_t digit = (k >> sh) & (BINS - 1);
     unsigned long long same = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < BITS; ++b) {
       const bool bit = (digit >> b) & 1u;
       const unsigned long long m = __ballot(bit && valid);
       same &= bit ? m : ~m;
     }
     const uint32_t rank = __popcll(same & ((1ull << lane) - 1ull));
-    uint32_t (*cnt)[256] = wave_cnt[r & 1];
+    uint32_t (*cnt)[BINS] = wave_cnt[r & 1];
     if (valid && rank == 0) cnt[wave][digit] = (uint32_t)__popcll(same);
     __syncthreads();
-    if (tid < 256) {
+    if (tid < BINS) {
       uint32_t run = digit_base[tid];
 #pragma unroll
       for (int w = 0; w < NW; ++w) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = run; run += c; }
@@ -308,7 +302,7 @@ __device__ __forceinline__ void wg_radix_pass(const uint32_t* kin, const uint32_
       kout[dst] = k;
       vout[dst] = v;
     }
-    for (int e = tid; e < NW * 256; e += NT) (&wave_cnt[(r + 1) & 1][0][0])[e] = 0;
+    for (int e = tid; e < NW * BINS; e += NT) (&wave_cnt[(r + 1) & 1][0][0])[e] = 0;
     __threadfence_block();   // (global ping-pong: this pass's stores are read by other threads of the workgroup in the next one)
     __syncthreads();
   }
@@ -321,9 +315,9 @@ __global__ __launch_bounds__(BUCKET_NT) void bucket_sort_kernel(int P, int lds_c
                                                                 uint32_t* __restrict__ sorted_id, uint2* __restrict__ sorted_rect) {
   constexpr int NT = BUCKET_NT, NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) uint32_t s_data[];   // keys[2][cap], vals[2][cap]
-  __shared__ uint32_t digit_base[256];
-  __shared__ uint32_t wave_cnt[2][NW][256];
-  __shared__ uint32_t wave_tot[4];
+  constexpr int BITS = 6;
+  __shared__ uint32_t digit_base[1 << BITS];
+  __shared__ uint32_t wave_cnt[2][NW][1 << BITS];
   const int view = blockIdx.y, bucket = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)view * P;
   const uint32_t start = bucket_off[(size_t)view * (MSD_BINS + 1) + bucket], end = bucket_off[(size_t)view * (MSD_BINS + 1) + bucket + 1];
@@ -333,8 +327,8 @@ __global__ __launch_bounds__(BUCKET_NT) void bucket_sort_kernel(int P, int lds_c
   } else if (n == 1) {
     if (tid == 0) { const uint32_t v = vals0[base + start]; sorted_id[base + start] = v; sorted_rect[base + start] = rect[base + v]; }
   } else {
-    // bits that can differ inside a bucket: the low 18 (sorted as three 8-bit digits), the whole key in the last bucket
-    const int passes = bucket == MSD_BINS - 1 ? 4 : 3;
+    // bits that can differ inside a bucket: the low 18 (three 6-bit digits), the whole key in the last bucket (six)
+    const int passes = bucket == MSD_BINS - 1 ? 6 : 3;
     const uint32_t* kf;
     const uint32_t* vf;
     if (n <= lds_cap) {
@@ -343,13 +337,13 @@ __global__ __launch_bounds__(BUCKET_NT) void bucket_sort_kernel(int P, int lds_c
       for (int i = tid; i < n; i += NT) { lk[0][i] = keys0[base + start + i]; lv[0][i] = vals0[base + start + i]; }
       __syncthreads();
       for (int p = 0; p < passes; ++p)
-        wg_radix_pass<NT>(lk[p & 1], lv[p & 1], lk[(p + 1) & 1], lv[(p + 1) & 1], n, 8 * p, digit_base, wave_cnt, wave_tot);
+        wg_radix_pass<NT, BITS>(lk[p & 1], lv[p & 1], lk[(p + 1) & 1], lv[(p + 1) & 1], n, BITS * p, digit_base, wave_cnt);
       kf = lk[passes & 1]; vf = lv[passes & 1];
     } else {
       uint32_t* gk[2] = {keys0 + base + start, keys1 + base + start};
       uint32_t* gv[2] = {vals0 + base + start, vals1 + base + start};
       for (int p = 0; p < passes; ++p)
-        wg_radix_pass<NT>(gk[p & 1], gv[p & 1], gk[(p + 1) & 1], gv[(p + 1) & 1], n, 8 * p, digit_base, wave_cnt, wave_tot);
+        wg_radix_pass<NT, BITS>(gk[p & 1], gv[p & 1], gk[(p + 1) & 1], gv[(p + 1) & 1], n, BITS * p, digit_base, wave_cnt);
       kf = gk[passes & 1]; vf = gv[passes & 1];
     }
     (void)kf;
