@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NT) void depth_sort_block_radix_kernel(int P, int N
 // Stable throughout and the initial order is index order, so depth ties resolve by ascending Gaussian index.
 constexpr uint32_t MSD_KEY_BASE = 0x3E4CCCCDu;   // bits of 0.2f
 constexpr int MSD_SHIFT = 18, MSD_BITS = 9, MSD_BINS = 1 << MSD_BITS;
-constexpr int BUCKET_LDS_CAP = 1024;   // (LDS per workgroup decides how many buckets a CU sorts at once: 1024 measured best)
+constexpr int BUCKET_LDS_CAP = 1024;
 
 __device__ __forceinline__ uint32_t msd_key(int P, int idx, size_t base, const float* depth, const int32_t* radii) {
   return radii[base + idx] > 0 ? __float_as_uint(depth[base + idx]) - MSD_KEY_BASE : 0xFFFFFFFFu;
@@ -385,7 +385,10 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
   }
   const int tile = u3d_radix_tile(d.P);
   const int nblk = (d.P + tile - 1) / tile;
-  static const int lds_cap = getenv("U3D_BUCKET_LDS_CAP") ? atoi(getenv("U3D_BUCKET_LDS_CAP")) : BUCKET_LDS_CAP;   // (tests force the global path)
+  // LDS per bucket workgroup decides how many buckets a CU sorts at once against how many take the global route: 1024 keys measured
+  // best up to 64 k Gaussians per view (C4), 4096 beyond (C5: denser buckets)
+  static const int lds_cap_env = getenv("U3D_BUCKET_LDS_CAP") ? atoi(getenv("U3D_BUCKET_LDS_CAP")) : 0;   // (tests force the global route)
+  const int lds_cap = lds_cap_env ? lds_cap_env : (d.P <= 65536 ? BUCKET_LDS_CAP : 4096);
 #define LAUNCH(NT, IT)                                                                                                       \
   do {                                                                                                                       \
     constexpr size_t lds = (size_t)2 * (NT / 64) * MSD_BINS * sizeof(uint32_t);                                              \
