@@ -83,15 +83,16 @@ def test_large_P_radix_sort_path(oracle_mod, P, level, compact):
 
 
 @pytest.mark.parametrize("F", [4096.0, 2097152.0])
-def test_radix_sort_far_depths(oracle_mod, F):
+@pytest.mark.parametrize("P", [6000, 2000])
+def test_radix_sort_far_depths(oracle_mod, F, P):
     """Depth keys far from the unit range: the whole scene scaled by a power of two F (positions, extents, camera translation: the
     image and every rounding are unchanged, every depth is F times larger), so that the radix digits that are constant in ordinary
-    scenes (the top byte of the depth bits) vary here."""
-    sc = scene(6000, 64, 80, seed=6, level="scene", compact=True, deg=1)
+    scenes (the top byte of the depth bits) vary here.  P = 2000 takes the one-workgroup LDS sort, P = 6000 the bucketed one (whose last bucket holds every depth beyond 13107.2)."""
+    sc = scene(P, 64, 80, seed=6, level="scene", compact=True, deg=1)
     V = sc["viewmatrix"].double()
     Pm = torch.linalg.inv(V) @ sc["projmatrix"].double()          # projmatrix = viewmatrix @ Pm (row-vector convention)
     V2 = V.clone(); V2[3, :3] *= F                                # p_view' = F p_view for p' = F p
-    z0 = torch.cat([sc["means3D"].double(), torch.ones(6000, 1, dtype=torch.float64)], 1) @ V[:, 2]
+    z0 = torch.cat([sc["means3D"].double(), torch.ones(P, 1, dtype=torch.float64)], 1) @ V[:, 2]
     too_near = (z0 > 0) & (z0 <= 0.25)                              # the near cull stays at 0.2: these would turn into giant splats
     sc["means3D"][too_near] -= ((z0[too_near] + 1.0)[:, None] * V[:3, 2][None, :]).float()    # ... put them behind the camera
     sc["means3D"] = sc["means3D"] * F
@@ -103,7 +104,7 @@ def test_radix_sort_far_depths(oracle_mod, F):
     dcol, dinv = cotangents(64, 80)
     color, invd, radii, g = _run_gpu(sc, dcol, dinv)
     r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
-    zv = (np.c_[to_numpy(sc)["means3D"].astype(np.float64), np.ones(6000)] @ V2.numpy())[:, 2]
+    zv = (np.c_[to_numpy(sc)["means3D"].astype(np.float64), np.ones(P)] @ V2.numpy())[:, 2]
     assert zv[r.radii > 0].min() > 0.2 * F and zv[r.radii > 0].max() > 4.0 * zv[r.radii > 0].min()
     assert np.array_equal(radii, r.radii) and near(color, r.color, r64.color)
     go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
