@@ -30,6 +30,7 @@ for cfgname in sys.argv[1:] or ["C2"]:
     torch.cuda.synchronize()
     npx = NV * H * W; al = lambda n: ((n + 255) // 256) * 256; T = ((H + 15) // 16) * ((W + 15) // 16)
     tl = image[al(npx * 4) * 2: al(npx * 4) * 2 + NV * T * 4].view(torch.int32).bitwise_and(0x7fffffff).float()   # bit 31: the tile ran the plain loop variant
+    plain = (image[al(npx * 4) * 2: al(npx * 4) * 2 + NV * T * 4].view(torch.int32) < 0).float().mean().item()   # bit 31
     lim = image[al(npx * 4):][: npx * 4].view(torch.int32)
-    print(cfgname, "tile_last mean %.1f median %.1f max %d frac>64 %.3f ; unsaturated pixels %d ; visible/view %.0f" % (
+    print(cfgname, "tiles on the plain loop variant %.3f ;" % plain, "tile_last mean %.1f median %.1f max %d frac>64 %.3f ; unsaturated pixels %d ; visible/view %.0f" % (
         tl.mean().item(), tl.median().item(), int(tl.max().item()), (tl > 64).float().mean().item(), int((lim == -1).sum()), (radii > 0).float().sum(1).mean().item()))
