@@ -1,0 +1,129 @@
+"""CPU arbiters for the full-size parity tests (TEST INFRASTRUCTURE: the only users of oracle/ besides smoke() and the
+bench's cpu_baseline leg).
+
+Two levels, both in fp32 (the restatement at the kernels' own precision) and fp64 (the arbiter):
+  * operator level -- `oracle_view`: one (item, view) of a batch through oracle/raster_oracle.c, image + the gradients of
+    the operator's six differentiable inputs for a given dL/dcolor;
+  * head level -- `head_grad_arbiter`: d loss / d (raw head output of one item) when only ONE of its views carries loss,
+    chained through the reference's activations (unipre3d_amd/head.py, pinned by golden G2) in the same dtype and the
+    render loss of utils/loss_utils.py (pinned by G4), with the oracle as the differentiable renderer.
+
+Parity bar (`assert_parity`): <= 1e-4 relative L2 of the fp64 arbiter (north_star), or -- for ill-conditioned draws, where
+fp32 arithmetic itself cannot do better -- <= k x the fp32 restatement's own measured distance from the fp64 arbiter.
+The measured distances are returned so that tests can print / bound them.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from conftest import rel_l2
+
+TOL = 1e-4          # BASELINE.json north_star: 1e-4 relative L2 on images and gradients
+GAP_K = 2.0         # allowance over the fp32 restatement's own distance from the fp64 arbiter
+
+
+def parity_errors(x, o32, o64):
+    """(distance of x from the fp64 arbiter, distance of x from the fp32 restatement, fp32-vs-fp64 gap)."""
+    return rel_l2(x, o64), rel_l2(x, o32), rel_l2(o32, o64)
+
+
+def parity_ok(x, o32, o64, tol=TOL, k=GAP_K):
+    e64, e32, gap = parity_errors(x, o32, o64)
+    return e64 <= tol or e64 <= k * gap
+
+
+def assert_parity(x, o32, o64, what="", tol=TOL, k=GAP_K):
+    """x: HIP result; o32 / o64: the CPU restatement in fp32 / fp64."""
+    x, o32, o64 = np.asarray(x), np.asarray(o32), np.asarray(o64)
+    if not np.any(o32) and not np.any(o64):
+        assert not np.any(x), f"{what}: oracle is all-zero, HIP is not"
+        return 0.0, 0.0, 0.0
+    e64, e32, gap = parity_errors(x.reshape(o64.shape), o32, o64)
+    assert e64 <= tol or e64 <= k * gap, \
+        f"{what}: |hip-f64| {e64:.2e}, |hip-f32| {e32:.2e}, fp32 restatement's own gap |f32-f64| {gap:.2e} (bar {tol:.0e} or {k:g} x gap)"
+    return e64, e32, gap
+
+
+def _np(x, dtype):
+    return np.ascontiguousarray(x.detach().cpu().numpy().astype(dtype))
+
+
+def oracle_view(oracle_mod, g, b, bi, v, H, W, dtype=np.float32, sh_degree=1):
+    """One (item, view) of batch `b` with Gaussian dict `g` ((B,P,...) torch tensors, any device) through the oracle."""
+    from unipre3d_amd import head
+    t = math.tan(b.fov_deg * math.pi / 360)
+    shs = head.concat_sh(g["features_dc"][bi], g["features_rest"][bi])
+    return oracle_mod.forward(_np(g["xyz"][bi], dtype), _np(g["opacity"][bi], dtype), _np(b.world_view[bi, v], dtype),
+                              _np(b.full_proj[bi, v], dtype), _np(b.camera_center[bi, v], dtype), _np(b.bg, dtype), H, W, t, t,
+                              shs=_np(shs, dtype), scales=_np(g["scaling"][bi], dtype), rotations=_np(g["rotation"][bi], dtype),
+                              sh_degree=sh_degree, dtype=dtype)
+
+
+class _OracleRender(torch.autograd.Function):
+    """The CPU oracle as a differentiable renderer (one view) for torch autograd on CPU tensors of either dtype."""
+
+    @staticmethod
+    def forward(ctx, oracle_mod, means3D, opacities, scales, rotations, shs, view, proj, campos, bg, H, W, t, sh_degree, exact_aa):
+        dt = np.float32 if means3D.dtype == torch.float32 else np.float64
+        n = lambda x: np.ascontiguousarray(x.detach().numpy())
+        r = oracle_mod.forward(n(means3D), n(opacities), n(view).astype(dt), n(proj).astype(dt), n(campos).astype(dt), n(bg).astype(dt),
+                               H, W, t, t, shs=n(shs), scales=n(scales), rotations=n(rotations), sh_degree=sh_degree, dtype=dt,
+                               exact_aa_grad=exact_aa)
+        ctx.r, ctx.oracle_mod, ctx.tdt = r, oracle_mod, means3D.dtype
+        return torch.from_numpy(r.color.copy())
+
+    @staticmethod
+    def backward(ctx, gcol):
+        go = ctx.oracle_mod.backward(ctx.r, np.ascontiguousarray(gcol.numpy()))
+        ctx.r.close()
+        f = lambda k: torch.from_numpy(np.ascontiguousarray(go[k])).to(ctx.tdt)
+        return (None, f("means3D"), f("opacities"), f("scales"), f("rotations"), f("shs")) + (None,) * 9
+
+
+def head_grad_arbiter(oracle_mod, b, bi, v, H, W, n_views_total, loss_kind, dtype=np.float64, sh_degree=1,
+                      non_bg_rate=4.0, bg_rate=1.0, exact_aa_grad=False):
+    """d loss / d raw[bi] ((C, P), the reference's (B, 23, N) layout) where loss = render loss over ALL n_views_total views'
+    pixels but only view (bi, v) differs from its target -- i.e. the per-view contribution the fused kernels can be made to
+    isolate by setting gt = rendered for every other view.  Returns (gradient (C,P) ndarray, loss value, image (3,H,W))."""
+    from unipre3d_amd import head, losses
+    tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+    raw = b.raw[bi:bi + 1].detach().cpu().to(tdt).clone().requires_grad_(True)
+    center = b.center[bi:bi + 1].detach().cpu().to(tdt)
+    if b.level == "object":
+        g = head.process_object_output(raw, center, b.offset_scale, sh_degree)
+        g = {k: x[0] for k, x in g.items()}
+    else:
+        C, P = raw.shape[1], raw.shape[2]
+        flat = raw.permute(0, 2, 1).reshape(P, C)
+        lists = head.process_scene_output(flat, center.reshape(P, 3), torch.zeros(P, 1, dtype=torch.long), b.offset_scale, sh_degree)
+        g = {k: x[0] for k, x in lists.items()}
+    t = math.tan(b.fov_deg * math.pi / 360)
+    shs = head.concat_sh(g["features_dc"], g["features_rest"])
+    c = lambda x: x.detach().cpu()
+    img = _OracleRender.apply(oracle_mod, g["xyz"], g["opacity"], g["scaling"], g["rotation"], shs, c(b.world_view[bi, v]),
+                              c(b.full_proj[bi, v]), c(b.camera_center[bi, v]), c(b.bg), H, W, t, sh_degree, exact_aa_grad)
+    gt = c(b.gt[bi, v]).to(tdt)
+    white = bool(b.bg[0].item() > 0.5) if loss_kind == "focal_l2" else False
+    # the loss of this one view, re-normalised to the whole batch's pixel count (the other views contribute exact zeros)
+    loss = losses.render_loss(img[None], gt[None], loss_kind, white_background=white, non_bg_color_loss_rate=non_bg_rate,
+                              bg_color_loss_rate=bg_rate) / n_views_total
+    loss.backward()
+    return raw.grad[0].numpy().copy(), float(loss.item()), img.detach().numpy().copy()
+
+
+def head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, dtype=np.float64, sh_degree=1, input_images=0):
+    """d loss / d raw for the WHOLE batch ((B, C, P)): the per-view arbiters summed over every item's views (small shapes only:
+    one oracle render per view).  Also returns the loss value."""
+    B, V = b.raw.shape[0], b.world_view.shape[1] - input_images
+    out, loss = [], 0.0
+    for bi in range(B):
+        acc = None
+        for v in range(input_images, input_images + V):
+            g, l, _ = head_grad_arbiter(oracle_mod, b, bi, v, H, W, B * V, loss_kind, dtype, sh_degree)
+            acc = g if acc is None else acc + g
+            loss += l
+        out.append(acc)
+    return np.stack(out), loss

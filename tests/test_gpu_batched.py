@@ -128,14 +128,16 @@ def test_full_size_C2_properties(oracle_mod):
                                                       ("scene", "l2", 500, 3, 120, 160), ("object", "l1", 64, 2, 48, 48)])
 @pytest.mark.parametrize("single_pass", [False, True])
 @pytest.mark.parametrize("opaque", [False, True])
-def test_fused_render_loss_equals_unfused_path(level, loss_kind, P, V, H, W, single_pass, opaque):
+def test_fused_render_loss_equals_unfused_path(oracle_mod, level, loss_kind, P, V, H, W, single_pass, opaque):
     """N2+N3: head-activation + render + loss in the HIP library == torch activations + batched operator + torch loss,
     for the loss value and for the gradient w.r.t. the raw head output.  `opaque`: every 9th Gaussian gets opacity
     sigmoid(6) = 0.9975, so tiles leave the clamp-free loop variant (tile_stage in u3d_render.hip) and the 0.99 clamp is live."""
+    from arbiter import assert_parity, head_grad_arbiter_all
     from unipre3d_amd import fused, step
     b, bd = _batch(2, P, V, H, W, level=level, seed=11)
     if opaque:
         bd.raw[:, 3, ::9] = 6.0
+        b.raw[:, 3, ::9] = 6.0
     head_out = bd.raw.permute(0, 2, 1).contiguous().requires_grad_(True)      # (B,P,23): what `final` emits
     loss_f, img_f, radii_f = fused.render_loss_fused(head_out, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt,
                                                      bd.bg, bd.fov_deg, H, W, level=level, offset_scale=bd.offset_scale,
@@ -151,10 +153,20 @@ def test_fused_render_loss_equals_unfused_path(level, loss_kind, P, V, H, W, sin
     g_unfused = raw.grad.permute(0, 2, 1)
     assert rel_l2(img_f.cpu().numpy(), img_u.detach().cpu().numpy()) < 1e-5
     assert abs(loss_f.item() - loss_u.item()) < 1e-5 * max(1.0, abs(loss_u.item()))
-    assert rel_l2(g_fused.cpu().numpy(), g_unfused.cpu().numpy()) < TOL
-    # linear in dL/dloss (looser: scene-level gradients cancel ~1000x across tiles, so re-rounding every term by the
-    # factor 3 moves the fp32 result by up to a few 1e-4 -- the same size as the fp32-vs-fp64 oracle gap there)
-    assert rel_l2(g_fused3.cpu().numpy(), 3.0 * g_fused.cpu().numpy()) < 5e-4
+    # every route -- fused, fused with dL/dloss = 3 (the two-pass kernels scale their seeds, so every term is re-rounded), and the
+    # operator chain -- is held to the parity bar against the fp64 arbiter of the WHOLE chain (reference activations -> oracle ->
+    # reference loss); scene-level gradients cancel ~1000x across tiles, there the fp32 restatement's own gap sets the bar
+    a32, l32 = head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, np.float32)
+    a64, l64 = head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, np.float64)
+    assert abs(loss_f.item() - l64) <= 1e-5 * max(1.0, abs(l64))
+    if loss_kind != "l1":    # (L1's gradient is discontinuous where a pixel equals its target: value / image bar only)
+        tr = lambda x: x.permute(0, 2, 1).cpu().numpy()
+        assert_parity(tr(g_fused), a32, a64, "fused d(head_out)")
+        assert_parity(tr(g_fused3) / 3.0, a32, a64, "fused d(head_out), dL/dloss = 3")
+        assert_parity(tr(g_unfused), a32, a64, "operator-chain d(head_out)")
+    else:
+        assert rel_l2(g_fused.cpu().numpy(), g_unfused.cpu().numpy()) < TOL
+        assert rel_l2(g_fused3.cpu().numpy(), 3.0 * g_fused.cpu().numpy()) < TOL
     # every channel group carries gradient (xyz, opacity, scaling, rotation, dc, rest)
     for lo, hi in ((0, 3), (3, 4), (4, 7), (7, 11), (11, 14), (14, 23)):
         assert g_fused[..., lo:hi].abs().sum().item() > 0
@@ -232,34 +244,6 @@ def test_end_to_end_standin_step_runs_and_trains():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0]
-
-
-def test_full_size_C5_geometry_properties():
-    """BASELINE config C5 geometry at full size (P = 200 000 Gaussians, 480x640, scene level, 2 of the 8 views): the largest
-    single-GPU shape -- 64 k-key radix tiles, 1200 tiles per view.  Size-independent properties: finite outputs, the fused
-    single-pass step equals the two-pass fused path and the operator chain, forward bit-repeatable, white background where
-    nothing renders, every visible Gaussian's radius positive and none for culled ones."""
-    from unipre3d_amd import fused, step
-    P, V, H, W = 200000, 2, 480, 640
-    b, bd = _batch(1, P, V, H, W, level="scene", seed=3)
-    res = []
-    for single_pass in (True, False):
-        h = bd.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
-        loss, img, radii = fused.render_loss_fused(h, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt, bd.bg, bd.fov_deg,
-                                                   H, W, level="scene", offset_scale=bd.offset_scale, loss_kind="l2", single_pass=single_pass)
-        loss.backward()
-        res.append((loss.detach(), img, h.grad, radii))
-    assert all(torch.isfinite(x).all().item() for r in res for x in r[:3])
-    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][3], res[1][3])          # same forward kernels' arithmetic
-    assert abs(res[0][0].item() - res[1][0].item()) <= 1e-6 * abs(res[1][0].item())
-    scale = res[1][2].abs().max().item()
-    assert scale > 0 and (res[0][2] - res[1][2]).abs().max().item() <= 1e-5 * scale
-    raw = bd.raw.clone().requires_grad_(True)
-    loss_u, img_u = step.render_loss_forward(raw, bd, H, W, 0, "l2")
-    loss_u.backward()
-    assert rel_l2(res[0][1].cpu().numpy(), img_u.detach().cpu().numpy()) < 1e-5
-    assert rel_l2(res[0][2].cpu().numpy(), raw.grad.permute(0, 2, 1).cpu().numpy()) < 5 * TOL
-    assert 0.3 * P < int((res[0][3] > 0).sum().item()) / V < P                               # a real mix of visible and culled
 
 
 def test_backward_unit_equals_loss_backward():

@@ -7,6 +7,7 @@ import torch
 
 from conftest import rel_l2
 from scenes import DIFF_KEYS, cotangents, scene, to_numpy
+from arbiter import assert_parity, head_grad_arbiter_all
 from test_gpu_parity import TOL, _run_gpu, near
 
 pytestmark = pytest.mark.gpu
@@ -36,16 +37,13 @@ def test_fuzz_forward_backward_vs_oracle(oracle_mod, P, H, W, level, compact, de
     g64 = oracle_mod.backward(r64, dcol.numpy().astype(np.float64), dinv.numpy().astype(np.float64))
     for k in DIFF_KEYS + ("means2D",):
         a = g[k].reshape(g32[k].shape)
-        if not np.any(g32[k]) and not np.any(g64[k]):
-            assert not np.any(a), k
-        else:
-            # ill-conditioned draws (a handful of huge splats): fp32 arithmetic -- the restatement's as much as the kernels' --
-            # sits up to ~1e-4 from the fp64 arbiter there (measured: restatement 4-8e-5 depending on its thread order, kernels
-            # 1.2-1.35e-4 on the rotation gradient of the P=7 draw), so those draws are held to 2e-4 of the deterministic fp64 result
-            assert near(a, g32[k], g64[k]) or rel_l2(a, g64[k]) < 2 * TOL, (k, rel_l2(a, g32[k]), rel_l2(a, g64[k]), rel_l2(g32[k], g64[k]))
+        # bar: 1e-4 of the fp64 arbiter, or -- ill-conditioned draws (a handful of huge splats), where fp32 arithmetic itself sits
+        # ~1e-4 from fp64 whatever its summation order (the restatement's gradient sum is multi-threaded: 4-8e-5 run to run on the
+        # P = 7 draw, the kernels 1.2-1.35e-4) -- 4 x the fp32 restatement's own measured distance from it
+        assert_parity(a, g32[k], g64[k], f"{k} P={P} {H}x{W} {level}", k=4.0)
 
 
-def test_fuzz_fused_paths_agree_on_random_shapes():
+def test_fuzz_fused_paths_agree_on_random_shapes(oracle_mod):
     """60 seeded draws (1-3 items, 1-3 views, images 1..129 px, P from 1 to 5000, both levels, three losses, compact and large
     splats): the single-pass fused step, the two-pass fused path and the torch-activations + batched-operator + torch-loss
     chain give the same loss, image and d loss / d head_out.  (L1's gradient is discontinuous where a pixel equals its
@@ -59,7 +57,8 @@ def test_fuzz_fused_paths_agree_on_random_shapes():
         H, W = int(rng.integers(1, 130)), int(rng.integers(1, 130))
         level = ("object", "scene")[int(rng.integers(0, 2))]
         kind = ("focal_l2", "l2", "l1")[int(rng.integers(0, 3))]
-        b = synthetic.make_batch(B, P, V, H, W, level=level, seed=int(rng.integers(0, 1 << 30)), compact=bool(rng.integers(0, 2))).to(dev)
+        bh = synthetic.make_batch(B, P, V, H, W, level=level, seed=int(rng.integers(0, 1 << 30)), compact=bool(rng.integers(0, 2)))
+        b = bh.to(dev)
         res = []
         for single_pass in (True, False):
             h = b.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
@@ -78,4 +77,8 @@ def test_fuzz_fused_paths_agree_on_random_shapes():
         scale = max(gu.abs().max().item(), 1e-30)
         assert (res[0][2] - res[1][2]).abs().max().item() <= 1e-6 * scale, tag        # same kernels' arithmetic, two schedules
         if kind != "l1" and gu.abs().sum().item() > 0:
-            assert rel_l2(res[0][2].cpu().numpy(), gu.cpu().numpy()) < 5 * TOL, tag
+            # both HIP routes against the fp64 arbiter of the whole chain (reference activations -> oracle -> reference loss)
+            a32, _ = head_grad_arbiter_all(oracle_mod, bh, H, W, kind, np.float32)
+            a64, _ = head_grad_arbiter_all(oracle_mod, bh, H, W, kind, np.float64)
+            assert_parity(res[0][2].permute(0, 2, 1).cpu().numpy(), a32, a64, f"fused {tag}", k=4.0)
+            assert_parity(gu.permute(0, 2, 1).cpu().numpy(), a32, a64, f"operator chain {tag}", k=4.0)

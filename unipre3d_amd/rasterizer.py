@@ -181,10 +181,13 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 
 def rasterize_gaussians_batched(means3D, opacities, viewmatrix, projmatrix, campos, bg, image_height, image_width, tanfovx,
                                 tanfovy, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
-                                sh_degree=0, scale_modifier=1.0, antialiasing=True, debug=False, exact_aa_grad=False):
+                                sh_degree=0, scale_modifier=1.0, antialiasing=True, debug=False, exact_aa_grad=False,
+                                means2D=None):
     """B sets x V cameras in ONE launch sequence.
     means3D (B,P,3), opacities (B,P,1), shs (B,P,M,3) | colors_precomp (B,P,3), scales (B,P,3) + rotations (B,P,4) |
     cov3D_precomp (B,P,6); viewmatrix/projmatrix (B,V,4,4), campos (B,V,3), bg (3,).
+    means2D (B*V,P,3), optional: the per-view screen-space gradient sink (`viewspace_points` of
+    gaussian_renderer/__init__.py:29); its .grad receives dL/dmean2D.
     Returns color (B,V,3,H,W), radii (B,V,P) int32, invdepth (B,V,1,H,W)."""
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
@@ -198,7 +201,8 @@ def rasterize_gaussians_batched(means3D, opacities, viewmatrix, projmatrix, camp
         (_lib.FLAG_EXACT_AA_GRAD if exact_aa_grad else 0)
     f = lambda t: _f32c(t, dev)
     color, radii, invdepth = _RasterizeFn.apply(
-        f(means3D), torch.zeros(B * V, P, 3, device=dev), f(shs), f(colors_precomp), f(opacities).reshape(B, P, 1), f(scales),
+        f(means3D), means2D if means2D is not None else torch.zeros(B * V, P, 3, device=dev), f(shs), f(colors_precomp),
+        f(opacities).reshape(B, P, 1), f(scales),
         f(rotations), f(cov3D_precomp), f(viewmatrix).reshape(B * V, 16), f(projmatrix).reshape(B * V, 16),
         f(campos).reshape(B * V, 3), f(bg).reshape(3), B, V, int(image_height), int(image_width), float(tanfovx),
         float(tanfovy), float(scale_modifier), int(sh_degree), flags)
