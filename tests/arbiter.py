@@ -127,3 +127,16 @@ def head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, dtype=np.float64, sh_d
             loss += l
         out.append(acc)
     return np.stack(out), loss
+
+
+def assert_radii(rd, r32, r64, what=""):
+    """radius = ceil(3 sqrt(lambda_max)) is an integer threshold: two fp32 evaluations (and fp32 vs fp64) land on different
+    sides of it for about one Gaussian in 2000 at radii of 10^3..10^4 px (measured at C3: the fp32 restatement itself differs
+    from the fp64 one in 0-2 of 2048 radii per view).  Bar: same visible set, every radius within 1 of the fp64 arbiter's, and
+    no more such off-by-ones than k x the fp32 restatement's own count (+2)."""
+    rd, r32, r64 = np.asarray(rd), np.asarray(r32), np.asarray(r64)
+    assert np.array_equal(rd > 0, r64 > 0) or np.array_equal(rd > 0, r32 > 0), f"{what}: visible sets differ"
+    n_hip, n_32 = int((rd != r64).sum()), int((r32 != r64).sum())
+    assert np.abs(rd.astype(np.int64) - r64).max(initial=0) <= 1, f"{what}: a radius is off by more than one"
+    assert n_hip <= GAP_K * n_32 + 2, f"{what}: {n_hip} radii differ from the fp64 arbiter (fp32 restatement: {n_32})"
+    return n_hip, n_32

@@ -23,6 +23,10 @@ import socket
 from datetime import timedelta
 from typing import Callable, Optional, Tuple
 
+# The host driver only supports dmabuf IPC: RCCL (and sharing HIP tensors across processes) needs this BEFORE the HIP/HSA
+# runtime initialises, i.e. before the first torch.cuda call of the process -- so it is set at import, not in init_from_env.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -30,6 +34,7 @@ import torch.nn as nn
 
 DEFAULT_TIMEOUT = timedelta(minutes=60)  # pointcept/engines/launch.py:21
 _LOCAL_RANK = 0
+_CTL = None   # gloo control group beside an RCCL default group (host-side barriers / scalar reductions)
 
 
 # ---- comm helpers (pointcept/utils/comm.py:23-88) -------------------------------------------
@@ -59,6 +64,28 @@ def synchronize() -> None:
         dist.barrier()
 
 
+def host_barrier() -> None:
+    """Barrier over the gloo control group (host side): rank rendezvous that does not touch RCCL -- timing brackets and the
+    launcher use it so that a broken collective library cannot take the collective-free render path down with it."""
+    if get_world_size() == 1:
+        return
+    dist.barrier(group=_CTL) if _CTL is not None else synchronize()
+
+
+def host_all_reduce_max(value: float) -> float:
+    """MAX over ranks of a host scalar (the 'max over ranks' of a timed region) through the gloo control group."""
+    if get_world_size() == 1:
+        return float(value)
+    if _CTL is None:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == dist.Backend.NCCL else torch.device("cpu")
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    t = torch.tensor([value], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CTL)
+    return float(t.item())
+
+
 def all_reduce_mean(x: torch.Tensor) -> torch.Tensor:
     """SUM then divide by world: the validation-PSNR reduction of train_network.py:253-256."""
     if get_world_size() > 1:
@@ -70,7 +97,7 @@ def all_reduce_mean(x: torch.Tensor) -> torch.Tensor:
 # ---- process group -------------------------------------------------------------------------
 def init_from_env(backend: Optional[str] = None, timeout: timedelta = DEFAULT_TIMEOUT) -> Tuple[int, int, int]:
     """Join the job described by the torch.distributed.run environment.  Returns (rank, local_rank, world)."""
-    global _LOCAL_RANK
+    global _LOCAL_RANK, _CTL
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     _LOCAL_RANK = int(os.environ.get("LOCAL_RANK", "0"))
@@ -79,11 +106,16 @@ def init_from_env(backend: Optional[str] = None, timeout: timedelta = DEFAULT_TI
         torch.cuda.set_device(_LOCAL_RANK % max(torch.cuda.device_count(), 1))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this driver
+        if "MASTER_PORT" not in os.environ:
+            raise RuntimeError("WORLD_SIZE > 1 needs MASTER_PORT (torch.distributed.run and dp.launch both set it): there is no "
+                               "safe default port for several jobs on one node")
         dist.init_process_group(backend=backend or ("nccl" if use_cuda else "gloo"), init_method="env://",
                                 world_size=world, rank=rank, timeout=timeout)
-        synchronize()
+        if dist.get_backend() == dist.Backend.NCCL:
+            # RCCL communicators are created lazily by the first device collective (DDP's parameter broadcast); rendezvous
+            # and host-side scalars go through a gloo group so that they never depend on it
+            _CTL = dist.new_group(backend="gloo", timeout=timeout)
+        host_barrier()
     return rank, _LOCAL_RANK, world
 
 
@@ -102,8 +134,15 @@ def _worker(local_rank: int, main_func: Callable, world: int, port: int, backend
     try:
         main_func(*args)
     finally:
-        if dist.is_initialized():
-            dist.destroy_process_group()
+        shutdown()
+
+
+def shutdown() -> None:
+    """Leave the job: destroy the process group(s) of this rank (no-op for a world of one)."""
+    global _CTL
+    if dist.is_available() and dist.is_initialized():
+        _CTL = None
+        dist.destroy_process_group()
 
 
 def launch(main_func: Callable, num_gpus_per_machine: int, cfg: tuple = (), backend: Optional[str] = None) -> None:
@@ -121,7 +160,10 @@ def launch(main_func: Callable, num_gpus_per_machine: int, cfg: tuple = (), back
 # ---- model wrap ----------------------------------------------------------------------------
 def create_ddp_model(model: nn.Module, *, sync_bn: bool = True, bucket_cap_mb: int = 128, **kwargs) -> nn.Module:
     """SyncBN conversion + DistributedDataParallel as ModelManager.setup_distributed does
-    (train_network.py:180-186; reference kwargs: broadcast_buffers=False, find_unused_parameters=True)."""
+    (train_network.py:180-186 -> pointcept/engines/defaults.py:22-43; the reference's kwargs broadcast_buffers=False and
+    find_unused_parameters=True are the defaults here too: its predictor has branches that do not run in every step, and DDP
+    hangs on a parameter that never produces a gradient unless it is told to look for them).  Pass
+    find_unused_parameters=False for a module known to use every parameter (saves DDP's per-step graph walk)."""
     if get_world_size() == 1:
         return model
     if sync_bn:
@@ -130,6 +172,7 @@ def create_ddp_model(model: nn.Module, *, sync_bn: bool = True, bucket_cap_mb: i
     if on_gpu and "device_ids" not in kwargs:
         kwargs["device_ids"] = [torch.cuda.current_device()]
     kwargs.setdefault("broadcast_buffers", False)
+    kwargs.setdefault("find_unused_parameters", True)
     kwargs.setdefault("gradient_as_bucket_view", True)
     return nn.parallel.DistributedDataParallel(model, bucket_cap_mb=bucket_cap_mb, **kwargs)
 
