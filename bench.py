@@ -10,6 +10,13 @@ A second timed region (reported under "train_step_with_head", not `value`) wraps
 Workload at N=1: BASELINE.json configs[1] (C2): transformer config, 128 Gaussians per object (1024 pts -> 128
 groups), 256x256, batch 32 per GPU x 4 supervised views = 128 rendered views per step.  Weak scaling: every
 rank renders its own 32 objects.  Prints ONE JSON line on rank 0.
+
+`--gpus N` with N > 1 and no torch.distributed.run environment starts the N ranks itself (one process per GPU, localhost
+rendezvous on a free port) the way the reference's launcher does (pointcept/engines/launch.py:75-88); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the ranks come from the environment.
+`value` is the collective-free render-loss hot path at every N (the path shards by object with no exchange step); the step
+that CONTAINS the path's one exchange (DDP all-reduce of the 117.9 MB of backbone + head gradients over RCCL, R9) is timed as
+`train_step_e2e_standin` at every N, with the same region's single-rank time measured in the same run beside it.
 """
 import argparse
 import json
@@ -114,26 +121,45 @@ def e2e_region(a, batch, dev, world, rank, B, V, H, W, loss_kind, timed):
     torch.manual_seed(43)
     net = PointTransformerStandIn().to(dev)
     nparam = sum(p.numel() for p in net.parameters())
-    net = dp.create_ddp_model(net, sync_bn=True)
-    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, eps=1e-15, fused=True)
 
-    def e2e_step():
-        opt.zero_grad(set_to_none=True)
-        head_out, center = net(pts, img, c2w, intr)
-        loss, _, _ = render_loss_fused(head_out, center, batch.world_view, batch.full_proj, batch.camera_center, batch.gt, batch.bg,
-                                       batch.fov_deg, H, W, level="object", offset_scale=1.0, loss_kind=loss_kind, return_images=False)
-        loss.backward()
-        if check_and_clip_gradients(net.parameters(), 1.0):
-            opt.step()
-        return loss.detach()
+    def make_step(model, optimizer):
+        def e2e_step():
+            optimizer.zero_grad(set_to_none=True)
+            head_out, center = model(pts, img, c2w, intr)
+            loss, _, _ = render_loss_fused(head_out, center, batch.world_view, batch.full_proj, batch.camera_center, batch.gt, batch.bg,
+                                           batch.fov_deg, H, W, level="object", offset_scale=1.0, loss_kind=loss_kind, return_images=False)
+            loss.backward()
+            if check_and_clip_gradients(model.parameters(), 1.0):
+                optimizer.step()
+            return loss.detach()
+        return e2e_step
 
     steps = max(5, min(a.steps, 20))
-    el, _, l = timed(e2e_step, False, steps=steps, warmup=3)
-    return {"value": world * B * V * steps / el, "unit": "views/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
-            "parameters": nparam, "gradient_bytes_all_reduced_per_step": 4 * nparam if world > 1 else 0, "final_loss": float(l),
-            "what": "1024-pt clouds -> FPS/ball-query/group (HIP) -> tokenizer + 16 transformer blocks (PyTorch-ROCm) -> 2D->3D fusion "
-                    "(HIP) -> final MLP -> fused render-loss fwd+bwd (HIP) -> " + ("DDP all-reduce + SyncBN (RCCL) -> " if world > 1 else "")
-                    + "NaN-check/clip -> AdamW; frozen SD-VAE excluded (synthetic decoder features)"}
+    solo = None
+    if world > 1:
+        # the SAME region on one rank's own batch without any exchange (every rank runs it at the same time, nothing is
+        # communicated): the single-GPU figure the DDP step below is to be compared with, measured in the same run
+        el1, _, _ = timed(make_step(net, torch.optim.AdamW(net.parameters(), lr=1e-4, eps=1e-15, fused=True)), False, steps=steps, warmup=3)
+        solo = {"ms_per_step": 1e3 * el1 / steps, "value": B * V * steps / el1, "unit": "views/s",
+                "what": "same step, same process, before the DDP wrap: no SyncBN, no all-reduce (max over the ranks running it concurrently)"}
+    # every parameter of the stand-in produces a gradient in every step, so DDP need not walk the graph for unused ones
+    # (the reference's predictor needs find_unused_parameters=True, which dp.create_ddp_model defaults to)
+    on_rccl = world > 1 and dist.get_backend() == dist.Backend.NCCL
+    # (SyncBN's all_gather has no gloo implementation for device tensors: the gloo-on-GPU test hook runs plain BN)
+    net = dp.create_ddp_model(net, sync_bn=on_rccl or world == 1, find_unused_parameters=False)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, eps=1e-15, fused=True)
+    el, _, l = timed(make_step(net, opt), False, steps=steps, warmup=3)
+    out = {"value": world * B * V * steps / el, "unit": "views/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+           "parameters": nparam, "gradient_bytes_all_reduced_per_step": 4 * nparam if world > 1 else 0,
+           "rccl_ranks": world if (world > 1 and dist.get_backend() == dist.Backend.NCCL) else 0,
+           "collective_backend": (str(dist.get_backend()) if world > 1 else None), "final_loss": float(l),
+           "what": "1024-pt clouds -> FPS/ball-query/group (HIP) -> tokenizer + 16 transformer blocks (PyTorch-ROCm) -> 2D->3D fusion "
+                   "(HIP) -> final MLP -> fused render-loss fwd+bwd (HIP) -> " + ("DDP bucketed all-reduce + SyncBN over RCCL/xGMI -> " if world > 1 else "")
+                   + "NaN-check/clip -> AdamW; frozen SD-VAE excluded (synthetic decoder features)"}
+    if solo:
+        out["n1_same_region"] = solo
+        out["speedup_over_n1_same_region"] = out["value"] / solo["value"]
+    return out
 
 
 def main():
@@ -151,6 +177,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no torch.distributed.run environment: start the ranks ourselves, one per GPU (pointcept/engines/launch.py:75-88)
+        sys.exit(dp.launch_script(os.path.abspath(__file__), sys.argv[1:], a.gpus,
+                                  share_devices=os.environ.get("U3D_BENCH_SHARE_GPU") == "1"))
     rank, local_rank, world = dp.init_from_env(os.environ.get("U3D_BENCH_BACKEND"))   # default: nccl (= RCCL) on GPUs
     if world != a.gpus:
         if rank == 0:
@@ -199,21 +229,18 @@ def main():
         steps = a.steps if steps is None else steps
         for _ in range(a.warmup if warmup is None else warmup):
             fn()
-        dp.synchronize()
         torch.cuda.synchronize()
+        dp.host_barrier()          # (gloo: the collective-free region never depends on RCCL)
         if profile:
             _lib.profile_begin(8 * (steps + 2) * 8, kinds, stride=prof_stride)
         t0 = time.perf_counter()
         for _ in range(steps):
             out = fn()
         torch.cuda.synchronize()
-        dp.synchronize()
+        dp.host_barrier()
         t1 = time.perf_counter()
         prof = _lib.profile_end() if profile else None
-        el = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        return el.item(), prof, out
+        return dp.host_all_reduce_max(t1 - t0), prof, out
 
     # timed region: HIP events only around every 4th launch of the dominant tile kernel(s) (a recorded scope idles the stream ~4-5 us);
     # the small kernels are timed in a short separate pass and merged into the per-kernel table below
@@ -383,8 +410,8 @@ def main():
         out.update(extras)
     emit()
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        dp.host_barrier()
+        dp.shutdown()
 
 
 def _read_num_rendered(g, batch, H, W, t) -> float:

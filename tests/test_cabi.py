@@ -160,3 +160,17 @@ def test_scratch_query_rejects_unsupported_shapes():
     assert lib.u3d_scratch_query(ctypes.byref(d), ctypes.byref(sizes)) == 2      # U3D_ERR_UNSUPPORTED
     d.n_items = 65535
     assert lib.u3d_scratch_query(ctypes.byref(d), ctypes.byref(sizes)) == 0
+
+
+def test_scratch_query_rejects_index_overflow(lib):
+    """Views x tiles, sets x Gaussians and (view, Gaussian) pairs are 32-bit indices inside the launchers: shapes whose products
+    leave that range come back as U3D_ERR_UNSUPPORTED instead of undefined behaviour."""
+    sizes = _lib.ScratchSizes()
+    ok = _lib.RasterDesc(1000, 60, 128, 4096, 4096, 0.5, 0.5, 1.0, 1, 4, 2)          # 60 000 views x 65 536 tiles > 2^31
+    assert lib.u3d_scratch_query(ctypes.byref(ok), ctypes.byref(sizes)) == 2
+    big_p = _lib.RasterDesc(60000, 1, 40000, 64, 64, 0.5, 0.5, 1.0, 1, 4, 2)         # 2.4e9 Gaussians
+    assert lib.u3d_scratch_query(ctypes.byref(big_p), ctypes.byref(sizes)) == 2
+    pairs = _lib.RasterDesc(2000, 30, 100000, 64, 64, 0.5, 0.5, 1.0, 1, 4, 2)        # 6e9 (view, Gaussian) pairs
+    assert lib.u3d_scratch_query(ctypes.byref(pairs), ctypes.byref(sizes)) == 2
+    fine = _lib.RasterDesc(32, 4, 128, 256, 256, 0.5, 0.5, 1.0, 1, 4, 2)
+    assert lib.u3d_scratch_query(ctypes.byref(fine), ctypes.byref(sizes)) == 0

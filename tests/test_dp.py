@@ -71,6 +71,12 @@ def test_check_and_clip_gradients_matches_reference_semantics():
         assert not check_and_clip_gradients(m1.parameters(), 1.0)
         m1.weight.grad[2, 3] = 0.0
     assert check_and_clip_gradients([torch.nn.Parameter(torch.zeros(3))], 1.0)   # no .grad at all
+    # finite gradients whose fp32 sum of squares overflows (norm ~ 4e20): the reference's isnan/isinf scan passes them and
+    # clip_grad_norm_ rescales -- so must this (the max-abs decides finiteness, not the overflowed L2 norm)
+    big = torch.nn.Parameter(torch.zeros(64))
+    big.grad = torch.full((64,), 5e19)
+    assert check_and_clip_gradients([big], 1.0)
+    assert torch.isfinite(big.grad).all() and abs(big.grad.double().norm().item() - 1.0) < 1e-4
 
 
 def test_standin_predictor_has_the_reference_parameter_counts():
@@ -85,3 +91,15 @@ def test_standin_predictor_has_the_reference_parameter_counts():
     assert total == 29_464_215 and abs(total * 4 / 1e6 - 117.9) < 0.1
     k = object_intrinsics(49.13434264120263, 128)
     assert abs(k[0, 0] - 140.0) < 1e-3 and k[0, 2] == 64.0                 # fx = fy = 140, cx = cy = 64
+
+
+def test_launch_script_starts_one_rank_per_process_and_joins_them(tmp_path):
+    """The `--gpus N` self-launch of bench.py: N fresh interpreters with the torch.distributed.run environment, localhost
+    rendezvous on a free port, gloo world of 2 on CPU; host-side barrier / MAX helpers; a failing rank ends the job."""
+    import json
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_script.py")
+    assert dp.launch_script(script, [str(tmp_path), "ok"], 2, backend="gloo") == 0
+    r = [json.load(open(os.path.join(tmp_path, f"script_rank{i}.json"))) for i in range(2)]
+    assert [x["rank"] for x in r] == [0, 1] and all(x["world"] == 2 and x["addr"] == "127.0.0.1" for x in r)
+    assert r[0]["port"] == r[1]["port"] and all(x["max"] == 11.0 and x["sum"] == 3.0 for x in r)
+    assert dp.launch_script(script, [str(tmp_path), "fail"], 2, backend="gloo") == 7

@@ -1,0 +1,45 @@
+"""bench.py as the driver runs it: the contract's JSON line, and the `--gpus N` self-launch (two ranks sharing cuda:0 over gloo --
+RCCL refuses two ranks on one device, so the collective library itself can only run on a multi-GPU node)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline")
+
+
+def _run(args, env=None, timeout=900):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                         env=dict(os.environ, **(env or {})))
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_single_gpu_small_config():
+    out = _run(["--config", "C1", "--steps", "5", "--warmup", "2", "--cpu-seconds", "1", "--no-e2e"])
+    for k in CONTRACT + ("cpu_baseline",):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 5 and out["scaling"] == "weak" and out["dtype"] == "f32"
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    assert abs(out["value"] - 8 * 5 / (out["ms_per_step"] * 5e-3)) < 1e-6 * out["value"]
+
+
+def test_bench_self_launches_two_ranks():
+    out = _run(["--gpus", "2", "--config", "C1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+               env={"U3D_BENCH_SHARE_GPU": "1", "U3D_BENCH_EXTRAS_BUDGET_S": "240"})
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["views_per_step"] == 16
+    assert abs(out["value"] - 16 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"]
+    e2e = out["train_step_e2e_standin"]
+    assert "error" not in e2e, e2e
+    assert e2e["collective_backend"] == "gloo" and e2e["gradient_bytes_all_reduced_per_step"] == 4 * 29_464_215
+    assert e2e["n1_same_region"]["ms_per_step"] > 0 and e2e["value"] > 0
+    assert "error" not in out["train_step_with_head"], out["train_step_with_head"]

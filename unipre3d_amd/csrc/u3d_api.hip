@@ -43,6 +43,12 @@ int check_desc(const u3d_raster_desc* d) {
   if (d->image_height > 65535 * U3D_TILE || d->image_width > 65535 * U3D_TILE) return U3D_ERR_UNSUPPORTED;
   if (d->sh_degree < 0 || d->sh_degree > 3) return U3D_ERR_UNSUPPORTED;
   if (!(d->tanfovx > 0.f) || !(d->tanfovy > 0.f)) return U3D_ERR_INVALID_ARGUMENT;
+  // the launchers index views, tiles and (view, Gaussian) pairs with 32-bit integers: refuse shapes whose products leave them
+  const long long NV = (long long)d->n_items * d->views_per_item;
+  const long long T = (long long)((d->image_width + U3D_TILE - 1) / U3D_TILE) * ((d->image_height + U3D_TILE - 1) / U3D_TILE);
+  if (NV >= (1ll << 31) || T >= (1ll << 31) || NV * T >= (1ll << 31)) return U3D_ERR_UNSUPPORTED;
+  if ((long long)d->n_items * d->P >= (1ll << 31)) return U3D_ERR_UNSUPPORTED;
+  if (NV * d->P >= (1ll << 32)) return U3D_ERR_UNSUPPORTED;   // sorted positions / pair ids are uint32
   return U3D_OK;
 }
 

@@ -157,6 +157,50 @@ def launch(main_func: Callable, num_gpus_per_machine: int, cfg: tuple = (), back
              daemon=False)
 
 
+def launch_script(script: str, argv, nproc: int, backend: Optional[str] = None, share_devices: bool = False,
+                  env_extra: Optional[dict] = None) -> int:
+    """Start `nproc` ranks of a SCRIPT on this node (one per GPU) and wait for them: what `python -m torch.distributed.run
+    --nproc-per-node N script` does, for entry points that take `--gpus N` themselves (bench.py) -- the script form of
+    `launch` above / of the reference's launcher (pointcept/engines/launch.py:75-88).  Each rank is a fresh interpreter with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT=<free port> in its environment (read by
+    `init_from_env`); rank 0 keeps the caller's stdout, the others' is dropped; the first failure ends the job.
+    share_devices: allow more ranks than HIP devices (test hook; RCCL refuses two ranks on one device, so the backend
+    defaults to gloo then).  Returns the job's exit code."""
+    import subprocess
+    import sys
+    if nproc > 1 and torch.cuda.is_available() and torch.cuda.device_count() < nproc and not share_devices:
+        print(f"[dp.launch_script] {nproc} ranks requested but only {torch.cuda.device_count()} HIP device(s) are visible", file=sys.stderr)
+        return 2
+    port = _find_free_port()
+    procs = []
+    for r in range(nproc):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend or share_devices:
+            env["U3D_BENCH_BACKEND"] = backend or "gloo"
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        import time
+        live = list(procs)
+        while live:
+            for pr in list(live):
+                code = pr.poll()
+                if code is not None:
+                    live.remove(pr)
+                    if code != 0:
+                        rc = rc or code
+                        for other in live:          # one rank died: the others would wait in a collective forever
+                            other.kill()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
 # ---- model wrap ----------------------------------------------------------------------------
 def create_ddp_model(model: nn.Module, *, sync_bn: bool = True, bucket_cap_mb: int = 128, **kwargs) -> nn.Module:
     """SyncBN conversion + DistributedDataParallel as ModelManager.setup_distributed does

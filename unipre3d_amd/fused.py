@@ -27,6 +27,8 @@ class _RenderLossFn(torch.autograd.Function):
             raise RuntimeError("the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback")
         B, P, C = head_out.shape
         NV = viewmatrix.shape[0]
+        if B == 0 or NV % B != 0:
+            raise ValueError(f"{NV} cameras for {B} Gaussian sets: every set needs the same number of views")
         V = NV // B
         K = (sh_degree + 1) ** 2
         if C != 11 + 3 * K:
@@ -82,6 +84,8 @@ class _RenderLossStepFn(torch.autograd.Function):
             raise RuntimeError("the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback")
         B, P, C = head_out.shape
         NV = viewmatrix.shape[0]
+        if B == 0 or NV % B != 0:
+            raise ValueError(f"{NV} cameras for {B} Gaussian sets: every set needs the same number of views")
         K = (sh_degree + 1) ** 2
         if C != 11 + 3 * K:
             raise ValueError(f"head output has {C} channels, expected {11 + 3 * K} for SH degree {sh_degree}")

@@ -36,6 +36,9 @@ class _ZBufferGather(torch.autograd.Function):
     def forward(ctx, camera_points, image_features, fx, fy, cx, cy):
         if camera_points.device.type != "cuda":
             raise RuntimeError("unipre3d_amd.fusion needs tensors on a HIP device; there is no CPU fallback")
+        if image_features.device != camera_points.device:
+            raise RuntimeError(f"unipre3d_amd.fusion: tensors on different devices ({camera_points.device}, {image_features.device})")
+        from .rasterizer import _stream_ptr
         B, N, _ = camera_points.shape
         _, C, H, W = image_features.shape
         cp, feat = camera_points.contiguous().float(), image_features.contiguous().float()
@@ -43,7 +46,7 @@ class _ZBufferGather(torch.autograd.Function):
         sel = torch.empty(B, N, dtype=torch.int32, device=cp.device)
         zbuf = torch.empty(B * H * W, dtype=torch.int32, device=cp.device)
         rc = load().u3d_zbuffer_fusion_forward(B, N, C, H, W, fx, fy, cx, cy, _lib.ptr(cp), _lib.ptr(feat), _lib.ptr(mapped),
-                                               _lib.ptr(sel), _lib.ptr(zbuf), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                               _lib.ptr(sel), _lib.ptr(zbuf), _stream_ptr(cp.device))
         if rc != 0:
             raise RuntimeError(f"u3d_zbuffer_fusion_forward failed with code {rc}")
         ctx.save_for_backward(sel)
@@ -57,8 +60,8 @@ class _ZBufferGather(torch.autograd.Function):
         B, N, C, H, W = ctx.shape
         grad_feat = torch.zeros(B, C, H, W, dtype=torch.float32, device=sel.device)
         g = grad_mapped.contiguous().float()
-        rc = load().u3d_zbuffer_fusion_backward(B, N, C, H, W, _lib.ptr(g), _lib.ptr(sel), _lib.ptr(grad_feat),
-                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        from .rasterizer import _stream_ptr
+        rc = load().u3d_zbuffer_fusion_backward(B, N, C, H, W, _lib.ptr(g), _lib.ptr(sel), _lib.ptr(grad_feat), _stream_ptr(sel.device))
         if rc != 0:
             raise RuntimeError(f"u3d_zbuffer_fusion_backward failed with code {rc}")
         return None, grad_feat, None, None, None, None

@@ -44,13 +44,37 @@ def _check(rc, what):
         raise RuntimeError(f"{what} failed with code {rc}")
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(dev=None):
+    """torch's current stream on the CURRENT device; tensors living on another device are refused (rasterizer._stream_ptr)."""
+    from .rasterizer import _stream_ptr
+    return _stream_ptr(dev)
 
 
-def _need_gpu(t):
-    if t.device.type != "cuda":
-        raise RuntimeError("unipre3d_amd.pointops needs tensors on a HIP device; there is no CPU fallback")
+def _need_gpu(*tensors):
+    dev = tensors[0].device
+    for t in tensors:
+        if t.device.type != "cuda":
+            raise RuntimeError("unipre3d_amd.pointops needs tensors on a HIP device; there is no CPU fallback")
+        if t.device != dev:
+            raise RuntimeError(f"unipre3d_amd.pointops: tensors on different devices ({dev} and {t.device})")
+    return dev
+
+
+def _f32(t, what):
+    """The kernels read raw fp32: anything else (fp16/bf16 under autocast, float64) is cast, never reinterpreted."""
+    if not t.is_floating_point():
+        raise TypeError(f"{what} must be a floating-point tensor, got {t.dtype}")
+    return t if t.dtype == torch.float32 else t.float()
+
+
+def _i32(idx, what):
+    """Index tensors are int32 in the C-ABI (what furthest_point_sample / ball_query return); int64 ones (.long(), torch.topk)
+    are converted, anything else is refused."""
+    if idx.dtype == torch.int32:
+        return idx
+    if idx.dtype == torch.int64:
+        return idx.to(torch.int32)
+    raise TypeError(f"{what} must be an int32 (or int64) index tensor, got {idx.dtype}")
 
 
 class FurthestPointSampling(Function):
@@ -58,11 +82,12 @@ class FurthestPointSampling(Function):
     def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
         """xyz (B,N,3) -> (B,npoint) int32 indices, starting from index 0 (subsample.py:77-100)."""
         assert xyz.is_contiguous()
-        _need_gpu(xyz)
+        dev = _need_gpu(xyz)
+        xyz = _f32(xyz, "xyz")
         B, N, _ = xyz.size()
         out = torch.empty(B, npoint, dtype=torch.int32, device=xyz.device)
         temp = torch.empty(B, N, dtype=torch.float32, device=xyz.device) if N > 8192 else None
-        _check(load().u3d_furthest_point_sampling(B, N, npoint, _lib.ptr(xyz), _lib.ptr(temp), _lib.ptr(out), _stream()), "fps")
+        _check(load().u3d_furthest_point_sampling(B, N, npoint, _lib.ptr(xyz), _lib.ptr(temp), _lib.ptr(out), _stream(dev)), "fps")
         return out
 
     @staticmethod
@@ -78,11 +103,12 @@ class GatherOperation(Function):
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         """features (B,C,N), idx (B,npoint) -> (B,C,npoint) (subsample.py:110-131)."""
         assert features.is_contiguous() and idx.is_contiguous()
-        _need_gpu(features)
+        dev = _need_gpu(features, idx)
+        features, idx = _f32(features, "features"), _i32(idx, "idx")
         B, npoint = idx.size()
         _, C, N = features.size()
         out = torch.empty(B, C, npoint, dtype=torch.float32, device=features.device)
-        _check(load().u3d_gather_points(B, C, N, npoint, _lib.ptr(features), _lib.ptr(idx), _lib.ptr(out), _stream()), "gather")
+        _check(load().u3d_gather_points(B, C, N, npoint, _lib.ptr(features), _lib.ptr(idx), _lib.ptr(out), _stream(dev)), "gather")
         ctx.for_backwards = (idx, C, N)
         return out
 
@@ -91,8 +117,9 @@ class GatherOperation(Function):
         idx, C, N = ctx.for_backwards
         B, npoint = idx.size()
         grad = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
-        g = grad_out.contiguous()
-        _check(load().u3d_gather_points_grad(B, C, N, npoint, _lib.ptr(g), _lib.ptr(idx), _lib.ptr(grad), _stream()), "gather grad")
+        g = _f32(grad_out, "grad_out").contiguous()
+        _check(load().u3d_gather_points_grad(B, C, N, npoint, _lib.ptr(g), _lib.ptr(idx), _lib.ptr(grad), _stream(_need_gpu(g, idx))),
+               "gather grad")
         return grad, None
 
 
@@ -110,11 +137,12 @@ class GroupingOperation(Function):
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         """features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample) (group.py:76-99)."""
         assert features.is_contiguous() and idx.is_contiguous()
-        _need_gpu(features)
+        dev = _need_gpu(features, idx)
+        features, idx = _f32(features, "features"), _i32(idx, "idx")
         B, npoint, nsample = idx.size()
         _, C, N = features.size()
         out = torch.empty(B, C, npoint, nsample, dtype=torch.float32, device=features.device)
-        _check(load().u3d_group_points(B, C, N, npoint, nsample, _lib.ptr(features.float()), _lib.ptr(idx), _lib.ptr(out), _stream()),
+        _check(load().u3d_group_points(B, C, N, npoint, nsample, _lib.ptr(features), _lib.ptr(idx), _lib.ptr(out), _stream(dev)),
                "group")
         ctx.for_backwards = (idx, N)
         return out
@@ -124,9 +152,9 @@ class GroupingOperation(Function):
         idx, N = ctx.for_backwards
         B, C, npoint, nsample = grad_out.size()
         grad = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
-        g = grad_out.contiguous()
-        _check(load().u3d_group_points_grad(B, C, N, npoint, nsample, _lib.ptr(g), _lib.ptr(idx), _lib.ptr(grad), _stream()),
-               "group grad")
+        g = _f32(grad_out, "grad_out").contiguous()
+        _check(load().u3d_group_points_grad(B, C, N, npoint, nsample, _lib.ptr(g), _lib.ptr(idx), _lib.ptr(grad),
+                                            _stream(_need_gpu(g, idx))), "group grad")
         return grad, None
 
 
@@ -138,11 +166,12 @@ class BallQuery(Function):
     def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
         """xyz (B,N,3) support, new_xyz (B,npoint,3) centres -> (B,npoint,nsample) int32 (group.py:175-196)."""
         assert new_xyz.is_contiguous() and xyz.is_contiguous()
-        _need_gpu(xyz)
+        dev = _need_gpu(xyz, new_xyz)
+        xyz, new_xyz = _f32(xyz, "xyz"), _f32(new_xyz, "new_xyz")
         B, N, _ = xyz.size()
         npoint = new_xyz.size(1)
         idx = torch.empty(B, npoint, nsample, dtype=torch.int32, device=xyz.device)
-        _check(load().u3d_ball_query(B, N, npoint, float(radius), nsample, _lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(idx), _stream()),
+        _check(load().u3d_ball_query(B, N, npoint, float(radius), nsample, _lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(idx), _stream(dev)),
                "ball query")
         return idx
 
