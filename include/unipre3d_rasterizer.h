@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define U3D_ABI_VERSION 1
+#define U3D_ABI_VERSION 2
 
 /* flags (fields 11-13 of GaussianRasterizationSettings, gaussian_renderer/__init__.py:56-58) */
 #define U3D_FLAG_PREFILTERED 1   /* accepted, no effect: culled points are dropped either way */
@@ -166,12 +166,20 @@ int u3d_render_loss_forward(const u3d_raster_desc* desc, const u3d_head_desc* he
                             int32_t* radii, float* loss_out, void* geom, void* binning, void* image, void* fused,
                             void* stream);
 
-/* Backward of the fused step: d_head_out [n_items][P][C] = dL/d(head_out) * dloss[0] (dloss: device scalar). */
+/*
+ * Backward of the fused step:
+ *   d_head_out [n_items][P][C] = d(head_out) of   dloss[0] * loss  +  <dL_dcolor_extra, out_color>
+ * dloss: device scalar dL/dloss.  dL_dcolor_extra [n_views][3][H][W] or NULL: the gradient of any further image-space term of
+ * the caller's objective with respect to the rendered images -- the reference's loss becomes
+ * `l12 + lambda_lpips * LPIPS(rendered, gt)` after `start_lpips_after` iterations (train_network.py:284-300); its dL/dcolor is
+ * added to the in-kernel loss seed, so that objective stays one launch sequence.
+ */
 int u3d_render_loss_backward(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss,
                              const float* bg, const float* head_out, const float* center, const float* viewmatrix,
                              const float* projmatrix, const float* campos, const float* gt, const int32_t* radii,
-                             const float* out_color, const float* dloss, const void* geom, const void* binning,
-                             const void* image, void* fused, void* backward_scratch, float* d_head_out, void* stream);
+                             const float* out_color, const float* dloss, const float* dL_dcolor_extra, const void* geom,
+                             const void* binning, const void* image, void* fused, void* backward_scratch, float* d_head_out,
+                             void* stream);
 
 /*
  * Training form of the fused step: forward AND backward in one launch sequence whose tile kernel blends, evaluates the

@@ -328,3 +328,49 @@ def test_single_pass_step_reuses_its_workspace_with_clean_accumulators(level, P,
             l1, g1 = step(bd)                                    # from the second step on: U3D_FLAG_ACC_CLEAN
             assert torch.equal(l1, l0) and torch.equal(g1, g0), (rnd, float((g1 - g0).abs().max()))
     assert len(fused._WS) == 1
+
+
+@pytest.mark.parametrize("level,loss_kind,P,V,H,W", [("object", "focal_l2", 128, 4, 96, 96), ("scene", "l2", 600, 2, 48, 80)])
+def test_fused_route_with_an_extra_image_space_term(oracle_mod, level, loss_kind, P, V, H, W):
+    """The reference's objective after `start_lpips_after` iterations is l12 + lambda_lpips * LPIPS(rendered, gt)
+    (train_network.py:284-300): the fused two-pass route returns differentiable images and adds dL/d(rendered) of such a term to
+    the in-kernel loss seed.  A fixed random perceptual-style term g(x) = mean(w * tanh(x)^2) stands in for the LPIPS network
+    (its weights are not available offline); fused(loss + 0.01 g) must equal the operator chain and the fp64 arbiter."""
+    from arbiter import assert_parity, head_grad_arbiter_all
+    from unipre3d_amd import fused, step
+    b, bd = _batch(2, P, V, H, W, level=level, seed=23)
+    wgt = torch.rand(2 * V, 3, H, W, generator=torch.Generator().manual_seed(1)).cuda()
+    g_img = lambda x: (wgt * torch.tanh(x) ** 2).mean()
+    h = bd.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+    loss, img, _ = fused.render_loss_fused(h, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt, bd.bg, bd.fov_deg, H, W,
+                                           level=level, offset_scale=bd.offset_scale, loss_kind=loss_kind, differentiable_images=True)
+    assert img.requires_grad
+    (loss + 0.01 * g_img(img)).backward()
+    raw = bd.raw.clone().requires_grad_(True)
+    loss_u, img_u = step.render_loss_forward(raw, bd, H, W, 0, loss_kind)
+    (loss_u + 0.01 * g_img(img_u)).backward()
+    e = rel_l2(h.grad.cpu().numpy(), raw.grad.permute(0, 2, 1).cpu().numpy())
+    # the image term ALONE through the fused route (dL/dloss absent: the in-kernel seed must vanish)
+    h2 = bd.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+    _, img2, _ = fused.render_loss_fused(h2, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt, bd.bg, bd.fov_deg, H, W,
+                                         level=level, offset_scale=bd.offset_scale, loss_kind=loss_kind, differentiable_images=True)
+    g_img(img2).backward()
+    raw2 = bd.raw.clone().requires_grad_(True)
+    _, img_u2 = step.render_loss_forward(raw2, bd, H, W, 0, loss_kind)
+    g_img(img_u2).backward()
+    e2 = rel_l2(h2.grad.cpu().numpy(), raw2.grad.permute(0, 2, 1).cpu().numpy())
+    # bar: 1e-4, or the measured fp32 noise floor of this workload (distance of the fp32 restatement of the loss-only chain
+    # from its fp64 arbiter) where that is larger
+    a32, _ = head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, np.float32)
+    a64, _ = head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, np.float64)
+    gap = rel_l2(a32, a64)
+    assert e <= max(TOL, 2 * gap) and e2 <= max(TOL, 2 * gap), (e, e2, gap)
+    # single-pass images stay detached, and asking for gradient through them without the switch is refused loudly
+    h3 = bd.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+    _, img3, _ = fused.render_loss_fused(h3, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt, bd.bg, bd.fov_deg, H, W,
+                                         level=level, offset_scale=bd.offset_scale, loss_kind=loss_kind)
+    assert not img3.requires_grad
+    with pytest.raises(ValueError):
+        fused.render_loss_fused(h3, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt, bd.bg, bd.fov_deg, H, W,
+                                level=level, offset_scale=bd.offset_scale, loss_kind=loss_kind, differentiable_images=True,
+                                return_images=False)

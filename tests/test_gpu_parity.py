@@ -236,16 +236,31 @@ def test_truly_compact_splats_operator_level(oracle_mod, P, H, W, level):
         assert near(gr[k].reshape(go[k].shape), go[k], go64[k]), k
 
 
-def _tile_flags(color, H, W):
-    """tile_last words of the forward that produced `color` (image scratch saved for backward): (last position, ran-plain flag)."""
-    fn = color.grad_fn
-    while not type(fn).__name__.startswith("_Rasterize"):   # through the per-view select / reshape nodes
-        fn = fn.next_functions[0][0]
-    image = fn.saved_tensors[-1]
+def _tile_flags(sc):
+    """tile_last words of a forward over the C-ABI (image scratch): (last contributing position, ran-the-plain-variant flag) per tile,
+    plus the radii."""
+    import ctypes
+    from unipre3d_amd import _lib
+    from unipre3d_amd.rasterizer import _Plan
+    dev = torch.device("cuda:0")
+    t = {k: (v.to(dev).contiguous() if torch.is_tensor(v) else v) for k, v in sc.items()}
+    P, M = t["means3D"].shape[0], t["shs"].shape[1]
+    H, W = sc["image_height"], sc["image_width"]
+    plan = _Plan(1, 1, P, H, W, sc["tanfovx"], sc["tanfovy"], 1.0, sc["sh_degree"], M, _lib.FLAG_ANTIALIASING | _lib.FLAG_DEBUG)
+    u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+    geom, binning, image = u8(plan.sizes.geom_bytes), u8(plan.sizes.binning_bytes), u8(plan.sizes.image_bytes)
+    color, radii = torch.empty(1, 3, H, W, device=dev), torch.zeros(1, P, dtype=torch.int32, device=dev)
+    p = _lib.ptr
+    rc = _lib.load().u3d_rasterize_forward(ctypes.byref(plan.desc), p(t["bg"]), p(t["means3D"]), p(t["shs"]), p(None), p(t["opacities"]),
+                                           p(t["scales"]), p(t["rotations"]), p(None), p(t["viewmatrix"]), p(t["projmatrix"]), p(t["campos"]),
+                                           p(color), p(None), p(radii), p(geom), p(binning), p(image),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "u3d_rasterize_forward")
+    torch.cuda.synchronize()
     al = lambda n: ((n + 255) // 256) * 256
     T = ((H + 15) // 16) * ((W + 15) // 16)
     tl = image[al(H * W * 4) * 2:][: T * 4].view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
-    return tl & 0x7fffffff, (tl >> 31).astype(bool)
+    return (tl & 0x7fffffff, (tl >> 31).astype(bool)), radii[0].cpu().numpy()
 
 
 @pytest.mark.parametrize("P,fade,every", [(200, 1.0, 7), (700, 0.05, 50), (700, 0.05, 333)])
@@ -270,16 +285,8 @@ def test_loop_variants_high_opacity(oracle_mod, P, fade, every):
 def test_loop_variant_selection(oracle_mod):
     """Which tiles may take the plain variant: all of them for an ordinary scene, none of those a Gaussian with opacity > 0.98 or
     a nearly singular conic (a 20 m x 1 mm needle: b^2 within 1e-5 of a c) reaches before they saturate."""
-    from unipre3d_amd.rasterizer import rasterize_gaussians
-    dev = torch.device("cuda:0")
     H = W = 64
-
-    def flags(sc):
-        t = {k: (v.to(dev).requires_grad_(k in DIFF_KEYS) if torch.is_tensor(v) else v) for k, v in sc.items()}
-        color, radii, _ = rasterize_gaussians(t["means3D"], torch.zeros_like(t["means3D"]), t["shs"], None, t["opacities"], t["scales"],
-                                              t["rotations"], None, _settings(sc, t))
-        torch.cuda.synchronize()
-        return _tile_flags(color, H, W), radii.cpu().numpy()
+    flags = _tile_flags
 
     sc = scene(100, H, W, seed=5)
     sc["opacities"].clamp_(max=0.9)

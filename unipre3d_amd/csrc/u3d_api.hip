@@ -286,8 +286,9 @@ int u3d_render_loss_forward(const u3d_raster_desc* desc, const u3d_head_desc* he
 int u3d_render_loss_backward(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss,
                              const float* bg, const float* head_out, const float* center, const float* viewmatrix,
                              const float* projmatrix, const float* campos, const float* gt, const int32_t* radii,
-                             const float* out_color, const float* dloss, const void* geom, const void* binning,
-                             const void* image, void* fused, void* backward_scratch, float* d_head_out, void* stream) {
+                             const float* out_color, const float* dloss, const float* dL_dcolor_extra, const void* geom,
+                             const void* binning, const void* image, void* fused, void* backward_scratch, float* d_head_out,
+                             void* stream) {
   int rc = check_fused(desc, head, loss);
   if (rc != U3D_OK) return rc;
   const u3d_raster_desc& d = *desc;
@@ -308,7 +309,7 @@ int u3d_render_loss_backward(const u3d_raster_desc* desc, const u3d_head_desc* h
   const U3DLoss L = make_loss(d, *loss, gt, f.partial, dloss);
   {
     ProfScope ps(3, s);
-    u3d_launch_render_bwd(d, b, bg, nullptr, nullptr, out_color, L, acc, part, s);
+    u3d_launch_render_bwd(d, b, bg, dL_dcolor_extra, nullptr, out_color, L, acc, part, s);
   }
   const int C = head->channels;
   U3DGradSink sink{};

@@ -596,6 +596,16 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
       dinv[k] = 0.f;
       loss_seed(lc, loss_weight(lc, inside[k], g0[k], g1[k], g2[k]), sc, x0[k] - g0[k], x1[k] - g1[k], x2[k] - g2[k], dp0[k], dp1[k], dp2[k]);
     }
+    if (dL_dcolor) {
+      // a further image-space term of the caller's objective (the reference adds lambda * LPIPS(rendered) after iteration
+      // start_lpips_after, train_network.py:284-300): its dL/dcolor joins the in-kernel loss seed
+      float e0[4], e1[4], e2[4];
+      load4(dL_dcolor + cid0, vec, inside, e0);
+      load4(dL_dcolor + cid0 + npix, vec, inside, e1);
+      load4(dL_dcolor + cid0 + 2 * npix, vec, inside, e2);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { dp0[k] += e0[k]; dp1[k] += e1[k]; dp2[k] += e2[k]; }
+    }
   } else {
     load4(dL_dcolor + cid0, vec, inside, dp0);
     load4(dL_dcolor + cid0 + npix, vec, inside, dp1);

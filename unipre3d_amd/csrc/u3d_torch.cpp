@@ -1,0 +1,200 @@
+// torch binding of the drop-in operator: `_C.rasterize_gaussians` as a C++ autograd function over the C-ABI of
+// libunipre3d_rasterizer.so (include/unipre3d_rasterizer.h).  It is what the third-party package's own `_C` extension is to
+// its Python wrapper: the reference calls the operator once per object and view
+// (train_network.py:418-446 -> gaussian_renderer/__init__.py:89-97), 128 forward + 128 backward calls per C2 step, so the
+// per-call host cost IS the cost of that route.  This file holds no arithmetic: it validates, allocates outputs / scratch
+// with torch's caching allocator, takes torch's current HIP stream and calls the extern "C" entry points.
+//
+// Built by unipre3d_amd/csrc/Makefile with g++ against the installed torch headers (no HIP device code here).
+#include <torch/extension.h>
+
+#include <c10/hip/HIPStream.h>
+
+#include <array>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+
+#include "unipre3d_rasterizer.h"
+
+namespace {
+
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+struct Plan {
+  u3d_raster_desc d;
+  u3d_scratch_sizes s;
+  size_t o_binning, o_image, fwd_scratch;   // offsets inside the forward arena (256-byte aligned)
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+// descriptors are small PODs: cache the scratch sizes per distinct descriptor (the per-view route reuses ONE shape all step long).
+// Entries are never erased: backward nodes keep a pointer to theirs (unordered_map nodes are address-stable).
+const Plan& plan_for(const u3d_raster_desc& d) {
+  static std::mutex mu;
+  static std::unordered_map<std::string, Plan> cache;
+  std::string key(reinterpret_cast<const char*>(&d), sizeof(d));
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  Plan p{};
+  p.d = d;
+  const int rc = u3d_scratch_query(&p.d, &p.s);
+  TORCH_CHECK(rc == U3D_OK, "u3d_scratch_query failed: ", u3d_error_string(rc));
+  p.o_binning = align256(p.s.geom_bytes);
+  p.o_image = p.o_binning + align256(p.s.binning_bytes);
+  p.fwd_scratch = p.o_image + align256(p.s.image_bytes);
+  return cache.emplace(std::move(key), p).first->second;
+}
+
+inline const float* fptr(const Tensor& t) { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; }
+inline float* fptr_mut(Tensor& t) { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; }
+
+inline Tensor f32c(const Tensor& t, const c10::Device& dev) {
+  if (!t.defined()) return t;
+  if (t.device() == dev && t.scalar_type() == at::kFloat && t.is_contiguous()) return t;
+  return t.to(dev, at::kFloat).contiguous();
+}
+
+inline void* current_stream(const c10::Device& dev) {
+  // the kernels are enqueued on the calling thread's current HIP device: refuse tensors that live elsewhere
+  const auto cur = c10::hip::current_device();
+  TORCH_CHECK(dev.index() < 0 || dev.index() == cur, "tensors live on cuda:", (int)dev.index(), " but the current device is cuda:", (int)cur,
+              "; call under torch.cuda.device(...) (one process per GPU sets it once)");
+  return (void*)c10::hip::getCurrentHIPStream().stream();
+}
+
+struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
+  // (optional inputs travel as c10::optional: the C++ autograd function machinery records device / layout of every plain Tensor
+  // argument and refuses undefined ones)
+  using OptTensor = c10::optional<Tensor>;
+  static variable_list forward(AutogradContext* ctx, Tensor means3D, OptTensor means2D_, OptTensor shs_, OptTensor colors_, Tensor opac,
+                               OptTensor scales_, OptTensor rots_, OptTensor cov_, Tensor view, Tensor proj, Tensor campos, Tensor bg,
+                               int64_t n_items, int64_t vpi, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier,
+                               int64_t sh_degree, int64_t flags, bool single) {
+    // single: ONE view of ONE set with the reference operator's own tensor shapes (means3D (P,3) ... -> color (3,H,W)); no
+    // leading set / view dimension, so no unsqueeze / squeeze nodes surround the call in the autograd graph
+    const c10::Device dev = means3D.device();
+    TORCH_CHECK(dev.is_cuda(), "the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback "
+                               "(the CPU restatement lives in oracle/ and is test infrastructure only)");
+    auto val = [](const OptTensor& t) { return t.has_value() ? *t : Tensor(); };
+    const Tensor shs = val(shs_), colors = val(colors_), scales = val(scales_), rots = val(rots_), cov = val(cov_);
+    const int64_t P = means3D.numel() > 0 ? means3D.size(-2) : 0;
+    const int64_t M = shs.defined() ? shs.size(-2) : 0;
+    u3d_raster_desc d{};
+    d.n_items = (int32_t)n_items; d.views_per_item = (int32_t)vpi; d.P = (int32_t)P;
+    d.image_height = (int32_t)H; d.image_width = (int32_t)W;
+    d.tanfovx = (float)tanfovx; d.tanfovy = (float)tanfovy; d.scale_modifier = (float)scale_modifier;
+    d.sh_degree = (int32_t)sh_degree; d.sh_coeffs = (int32_t)M; d.flags = (int32_t)flags;
+    const Plan& plan = plan_for(d);
+    const int64_t NV = n_items * vpi;
+    const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+    Tensor color = single ? at::empty({3, H, W}, fopt) : at::empty({NV, 3, H, W}, fopt);
+    Tensor invdepth = single ? at::empty({1, H, W}, fopt) : at::empty({NV, 1, H, W}, fopt);
+    // (every (view, Gaussian) radius is written by the projection kernel)
+    Tensor radii = single ? at::empty({P}, fopt.dtype(at::kInt)) : at::empty({NV, P}, fopt.dtype(at::kInt));
+    Tensor arena = at::empty({(int64_t)plan.fwd_scratch}, fopt.dtype(at::kByte));   // geom | binning | image
+    char* base = (char*)arena.data_ptr();
+    const int rc = u3d_rasterize_forward(&plan.d, fptr(bg), fptr(means3D), fptr(shs), fptr(colors), fptr(opac), fptr(scales), fptr(rots),
+                                         fptr(cov), fptr(view), fptr(proj), fptr(campos), color.data_ptr<float>(), invdepth.data_ptr<float>(),
+                                         P > 0 ? radii.data_ptr<int32_t>() : nullptr, base, base + plan.o_binning, base + plan.o_image,
+                                         current_stream(dev));
+    TORCH_CHECK(rc == U3D_OK, "u3d_rasterize_forward failed: ", u3d_error_string(rc), " (code ", rc, ")");
+    ctx->saved_data["plan"] = (int64_t)(intptr_t)&plan;      // (cache entries are never moved: unordered_map nodes are stable)
+    ctx->saved_data["has_colors"] = colors.defined();
+    ctx->saved_data["single"] = single;
+    ctx->save_for_backward({means3D, shs, colors, opac, scales, rots, cov, view, proj, campos, bg, radii, arena});
+    ctx->mark_non_differentiable({radii});
+    ctx->set_materialize_grads(false);    // unused outputs (invdepth) arrive undefined, not as a zero tensor
+    return {color, radii, invdepth};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const Plan& plan = *(const Plan*)(intptr_t)ctx->saved_data["plan"].toInt();
+    const bool has_colors = ctx->saved_data["has_colors"].toBool();
+    const bool single = ctx->saved_data["single"].toBool();
+    auto sv = ctx->get_saved_variables();
+    const Tensor &means3D = sv[0], &shs = sv[1], &colors = sv[2], &opac = sv[3], &scales = sv[4], &rots = sv[5], &cov = sv[6], &view = sv[7],
+                 &proj = sv[8], &campos = sv[9], &bg = sv[10], &radii = sv[11], &arena = sv[12];
+    const u3d_raster_desc& d = plan.d;
+    const c10::Device dev = means3D.device();
+    const int64_t NV = (int64_t)d.n_items * d.views_per_item, P = d.P, M = d.sh_coeffs, n = d.n_items;
+    const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+    Tensor gcol = grads[0], ginv = grads[2];
+    if (gcol.defined()) gcol = f32c(gcol, dev);
+    else gcol = at::zeros({NV * 3, d.image_height, d.image_width}, fopt);     // only the inverse-depth output was used downstream
+    if (ginv.defined()) ginv = f32c(ginv, dev);
+    const bool live = P > 0 && NV > 0;
+    // the backward kernels write every element of every gradient they are handed (zeros for culled / untouched Gaussians)
+    auto out = [&](std::initializer_list<int64_t> shape) {
+      std::vector<int64_t> sh(shape.begin() + (single ? 1 : 0), shape.end());     // single: drop the leading set / view dimension
+      return live ? at::empty(sh, fopt) : at::zeros(sh, fopt);
+    };
+    Tensor g_means3D = out({n, P, 3}), g_means2D = out({NV, P, 3}), g_op = out({n, P, 1});
+    Tensor g_shs = shs.defined() ? out({n, P, M, 3}) : Tensor();
+    Tensor g_col = has_colors ? out({n, P, 3}) : Tensor();
+    Tensor g_scales = scales.defined() ? out({n, P, 3}) : Tensor();
+    Tensor g_rots = scales.defined() ? out({n, P, 4}) : Tensor();
+    Tensor g_cov = cov.defined() ? out({n, P, 6}) : Tensor();
+    if (live) {
+      Tensor scratch = at::empty({(int64_t)plan.s.backward_bytes}, fopt.dtype(at::kByte));
+      const char* base = (const char*)arena.data_ptr();
+      const int rc = u3d_rasterize_backward(&plan.d, fptr(bg), fptr(means3D), fptr(shs), fptr(colors), fptr(opac), fptr(scales), fptr(rots),
+                                            fptr(cov), fptr(view), fptr(proj), fptr(campos), radii.data_ptr<int32_t>(), fptr(gcol), fptr(ginv),
+                                            base, base + plan.o_binning, base + plan.o_image, scratch.data_ptr(), fptr_mut(g_means3D),
+                                            fptr_mut(g_means2D), fptr_mut(g_shs), fptr_mut(g_col), fptr_mut(g_op), fptr_mut(g_scales),
+                                            fptr_mut(g_rots), fptr_mut(g_cov), current_stream(dev));
+      TORCH_CHECK(rc == U3D_OK, "u3d_rasterize_backward failed: ", u3d_error_string(rc), " (code ", rc, ")");
+    }
+    return {g_means3D, g_means2D, g_shs, g_col, g_op, g_scales, g_rots, g_cov, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+            Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+// empty tensors count as absent (upstream's convention for colors_precomp / cov3D_precomp); present ones become contiguous fp32 on `dev`
+inline c10::optional<Tensor> opt(const c10::optional<Tensor>& t, const c10::Device& dev) {
+  if (t.has_value() && t->defined() && t->numel() > 0) return f32c(*t, dev);
+  return c10::nullopt;
+}
+
+// Batched form: leading dimension = sets for the Gaussian parameters, = views for cameras and outputs.
+std::tuple<Tensor, Tensor, Tensor> rasterize_batched(const Tensor& means3D, const c10::optional<Tensor>& means2D, const c10::optional<Tensor>& shs,
+                                                     const c10::optional<Tensor>& colors, const Tensor& opac, const c10::optional<Tensor>& scales,
+                                                     const c10::optional<Tensor>& rots, const c10::optional<Tensor>& cov, const Tensor& view,
+                                                     const Tensor& proj, const Tensor& campos, const Tensor& bg, int64_t n_items, int64_t vpi,
+                                                     int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier,
+                                                     int64_t sh_degree, int64_t flags) {
+  const c10::Device dev = means3D.device();
+  auto f = [&](const c10::optional<Tensor>& t) { return opt(t, dev); };
+  auto r = RasterizeFn::apply(f32c(means3D, dev), f(means2D), f(shs), f(colors), f32c(opac, dev), f(scales), f(rots), f(cov), f32c(view, dev),
+                              f32c(proj, dev), f32c(campos, dev), f32c(bg, dev), n_items, vpi, H, W, tanfovx, tanfovy, scale_modifier, sh_degree,
+                              flags, false);
+  return {r[0], r[1], r[2]};
+}
+
+// One view: the reference's operator call (gaussian_renderer/__init__.py:89-97).  means3D (P,3), means2D (P,3) gradient sink,
+// shs (P,M,3) | colors (P,3), opacities (P,1), scales (P,3) + rotations (P,4) | cov3D (P,6); cameras (4,4), (4,4), (3,), bg (3,).
+std::tuple<Tensor, Tensor, Tensor> rasterize_view(const Tensor& means3D, const c10::optional<Tensor>& means2D, const c10::optional<Tensor>& shs,
+                                                  const c10::optional<Tensor>& colors, const Tensor& opac, const c10::optional<Tensor>& scales,
+                                                  const c10::optional<Tensor>& rots, const c10::optional<Tensor>& cov, const Tensor& view,
+                                                  const Tensor& proj, const Tensor& campos, const Tensor& bg, int64_t H, int64_t W,
+                                                  double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree, int64_t flags) {
+  const c10::Device dev = means3D.device();
+  auto f = [&](const c10::optional<Tensor>& t) { return opt(t, dev); };
+  auto r = RasterizeFn::apply(f32c(means3D, dev), f(means2D), f(shs), f(colors), f32c(opac, dev), f(scales), f(rots), f(cov), f32c(view, dev),
+                              f32c(proj, dev), f32c(campos, dev), f32c(bg, dev), 1, 1, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, flags,
+                              true);
+  return {r[0], r[1], r[2]};
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "torch binding of libunipre3d_rasterizer.so (include/unipre3d_rasterizer.h)";
+  m.def("rasterize_view", &rasterize_view, "one view: the reference's per-view operator call");
+  m.def("rasterize_batched", &rasterize_batched, "n_items sets x views_per_item cameras in one launch sequence");
+  m.def("abi_version", []() { return u3d_abi_version(); });
+}

@@ -49,23 +49,28 @@ class _RenderLossFn(torch.autograd.Function):
         _lib.check(rc, "u3d_render_loss_forward")
         ctx.plan, ctx.hd, ctx.ld = plan, hd, ld
         ctx.save_for_backward(head_out, center, viewmatrix, projmatrix, campos, gt, bg, color, radii, geom, binning, image, fused)
-        ctx.mark_non_differentiable(color, radii)
+        ctx.mark_non_differentiable(radii)     # `color` stays differentiable: an image-space term (LPIPS) may hang off it
         ctx.set_materialize_grads(False)
         return loss, color, radii
 
     @staticmethod
-    def backward(ctx, grad_loss, _gc, _gr):
+    def backward(ctx, grad_loss, grad_color, _gr):
         lib = _lib.load()
         head_out, center, viewmatrix, projmatrix, campos, gt, bg, color, radii, geom, binning, image, fused = ctx.saved_tensors
         dev = head_out.device
-        if grad_loss is None:
+        if grad_loss is None and grad_color is None:
             return (torch.zeros_like(head_out),) + (None,) * 17
         d_head = torch.empty_like(head_out)
         scratch = torch.empty(ctx.plan.sizes.backward_bytes, dtype=torch.uint8, device=dev)
-        dloss = _f32c(grad_loss, dev).reshape(1)
+        dloss = _f32c(grad_loss, dev).reshape(1) if grad_loss is not None else torch.zeros(1, dtype=torch.float32, device=dev)
+        extra = None
+        if grad_color is not None:             # dL/d(rendered) of a further image-space term of the objective (train_network.py:284-300)
+            if grad_color.shape != color.shape:
+                raise RuntimeError(f"gradient of the rendered images has shape {tuple(grad_color.shape)}, expected {tuple(color.shape)}")
+            extra = _f32c(grad_color, dev)
         p = _lib.ptr
         rc = lib.u3d_render_loss_backward(ctypes.byref(ctx.plan.desc), ctypes.byref(ctx.hd), ctypes.byref(ctx.ld), p(bg), p(head_out),
-                                          p(center), p(viewmatrix), p(projmatrix), p(campos), p(gt), p(radii), p(color), p(dloss),
+                                          p(center), p(viewmatrix), p(projmatrix), p(campos), p(gt), p(radii), p(color), p(dloss), p(extra),
                                           p(geom), p(binning), p(image), p(fused), p(scratch), p(d_head), _stream_ptr(dev))
         _lib.check(rc, "u3d_render_loss_backward")
         return (d_head,) + (None,) * 17
@@ -161,12 +166,16 @@ def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: 
                       level: str = "object", offset_scale: float = 1.0, max_sh_degree: int = 1, loss_kind: str = "focal_l2",
                       non_bg_color_loss_rate: float = 4.0, bg_color_loss_rate: float = 1.0, input_images: int = 0,
                       scaling_modifier: float = 1.0, antialiasing: bool = True, debug: bool = False,
-                      single_pass: bool = True, return_images: bool = True):
+                      single_pass: bool = True, return_images: bool = True, differentiable_images: bool = False):
     """head_out (B,P,C) point-major raw head output (C = 23 at SH degree 1), center (B,P,3), cameras (B,Vtot,...),
-    gt (B,Vtot,3,H,W).  Returns (loss scalar, rendered (B*V',3,H,W) detached, radii (B*V',P)).
+    gt (B,Vtot,3,H,W).  Returns (loss scalar, rendered (B*V',3,H,W), radii (B*V',P)).
     single_pass (default): when a gradient is wanted, forward and backward run as ONE launch sequence
-    (u3d_render_loss_step) and autograd's backward only scales the stored gradient; return_images=False additionally
-    skips writing the rendered images (the training loop only needs the loss)."""
+    (u3d_render_loss_step) and autograd's backward only scales the stored gradient; the rendered images it returns are
+    DETACHED (requires_grad False); return_images=False additionally skips writing them (the training loop only needs the loss).
+    differentiable_images=True: the objective has a further image-space term -- the reference's
+    `l12 + lambda_lpips * lpips(rendered, gt)` after `start_lpips_after` iterations (train_network.py:284-300).  The call then
+    takes the two-pass route, the returned images carry gradient, and `(loss + lam * g(rendered)).backward()` adds
+    dL/d(rendered) to the in-kernel loss seed (u3d_render_loss_backward's dL_dcolor_extra): still one launch sequence each way."""
     dev = head_out.device
     B = head_out.shape[0]
     wv, fp, cc = world_view[:, input_images:], full_proj[:, input_images:], camera_center[:, input_images:]
@@ -174,7 +183,9 @@ def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: 
     t = math.tan(fov_deg * math.pi / 360)
     flags = (_lib.FLAG_ANTIALIASING if antialiasing else 0) | (_lib.FLAG_DEBUG if debug else 0)
     f = lambda x: _f32c(x, dev)
-    if single_pass and head_out.requires_grad and torch.is_grad_enabled():
+    if differentiable_images and not return_images:
+        raise ValueError("differentiable_images=True needs return_images=True")
+    if single_pass and not differentiable_images and head_out.requires_grad and torch.is_grad_enabled():
         return _RenderLossStepFn.apply(f(head_out), f(center), f(wv).reshape(NV, 16), f(fp).reshape(NV, 16), f(cc).reshape(NV, 3),
                                        f(gt[:, input_images:]).reshape(NV, 3, H, W), f(bg).reshape(3), int(H), int(W), float(t),
                                        1 if level == "object" else 2, float(offset_scale), int(max_sh_degree), loss_kind,

@@ -5,7 +5,8 @@ Mirrors what gaussian_renderer/__init__.py:8,45-61,89-97 needs from `diff_gaussi
 keyword that returns the 3-tuple (color (3,H,W), radii (P,) int32, invdepth (1,H,W)) and is
 differentiable w.r.t. means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
 cov3D_precomp.  The arithmetic runs in libunipre3d_rasterizer.so (hand-written gfx950 kernels) on
-torch's CURRENT stream, with no device->host synchronisation.
+torch's CURRENT stream, with no device->host synchronisation; the autograd function around it is C++
+(csrc/u3d_torch.cpp, loaded by `_C()`), because the reference calls the operator once per object and view.
 
 `rasterize_gaussians_batched` is the same operator for B sets x V cameras in one launch sequence
 (replaces the Python loop of train_network.py:418-446).
@@ -13,6 +14,7 @@ torch's CURRENT stream, with no device->host synchronisation.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -87,72 +89,30 @@ def _stream_ptr(dev=None):
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-class _RasterizeFn(torch.autograd.Function):
-    """forward/backward pair over the C-ABI.  Tensor layout: leading dim = sets (items) for Gaussian
-    parameters, leading dim = views for cameras and outputs."""
+_BINDING_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "_u3d_torch.so")
+_binding = None
 
-    @staticmethod
-    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
-                projmatrix, campos, bg, n_items, vpi, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, flags):
-        lib = _lib.load()
-        dev = means3D.device
-        if dev.type != "cuda":
-            raise RuntimeError("the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback "
-                               "(the CPU restatement lives in oracle/ and is test infrastructure only)")
-        P = means3D.shape[-2] if means3D.numel() > 0 else 0
-        M = shs.shape[-2] if shs is not None else 0
-        plan = _Plan(n_items, vpi, P, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, M, flags)
-        NV = n_items * vpi
-        color = torch.empty((NV, 3, H, W), dtype=torch.float32, device=dev)
-        invdepth = torch.empty((NV, 1, H, W), dtype=torch.float32, device=dev)
-        radii = torch.zeros((NV, P), dtype=torch.int32, device=dev)
-        geom = torch.empty(plan.sizes.geom_bytes, dtype=torch.uint8, device=dev)
-        binning = torch.empty(plan.sizes.binning_bytes, dtype=torch.uint8, device=dev)
-        image = torch.empty(plan.sizes.image_bytes, dtype=torch.uint8, device=dev)
-        p = _lib.ptr
-        rc = lib.u3d_rasterize_forward(ctypes.byref(plan.desc), p(bg), p(means3D), p(shs), p(colors_precomp), p(opacities),
-                                       p(scales), p(rotations), p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos),
-                                       p(color), p(invdepth), p(radii), p(geom), p(binning), p(image), _stream_ptr(dev))
-        _lib.check(rc, "u3d_rasterize_forward")
-        ctx.plan = plan
-        ctx.has = (shs is not None, colors_precomp is not None, scales is not None, cov3D_precomp is not None)
-        ctx.save_for_backward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
-                              projmatrix, campos, bg, radii, geom, binning, image)
-        ctx.mark_non_differentiable(radii)
-        ctx.set_materialize_grads(False)   # unused outputs (invdepth) arrive as None, not as a zero tensor
-        return color, radii, invdepth
 
-    @staticmethod
-    def backward(ctx, grad_color, _grad_radii, grad_invdepth):
-        lib = _lib.load()
-        (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, bg,
-         radii, geom, binning, image) = ctx.saved_tensors
-        plan = ctx.plan
-        d = plan.desc
-        dev = means3D.device
-        NV, P, M = d.n_items * d.views_per_item, d.P, d.sh_coeffs
-        if grad_color is None:      # only the inverse-depth output was used downstream
-            grad_color = torch.zeros((NV, 3, d.image_height, d.image_width), dtype=torch.float32, device=dev)
-        grad_color = _f32c(grad_color, dev)
-        grad_invdepth = _f32c(grad_invdepth, dev) if grad_invdepth is not None else None
-        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-        g_means3D, g_means2D, g_op = z(d.n_items, P, 3), z(NV, P, 3), z(d.n_items, P, 1)
-        g_shs = z(d.n_items, P, M, 3) if shs is not None else None
-        g_col = z(d.n_items, P, 3)
-        g_scales = z(d.n_items, P, 3) if scales is not None else None
-        g_rot = z(d.n_items, P, 4) if scales is not None else None
-        g_cov = z(d.n_items, P, 6) if cov3D_precomp is not None else None
-        if P > 0 and NV > 0:
-            scratch = torch.empty(plan.sizes.backward_bytes, dtype=torch.uint8, device=dev)
-            p = _lib.ptr
-            rc = lib.u3d_rasterize_backward(
-                ctypes.byref(d), p(bg), p(means3D), p(shs), p(colors_precomp), p(opacities), p(scales), p(rotations),
-                p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos), p(radii), p(grad_color), p(grad_invdepth),
-                p(geom), p(binning), p(image), p(scratch), p(g_means3D), p(g_means2D), p(g_shs), p(g_col), p(g_op),
-                p(g_scales), p(g_rot), p(g_cov), _stream_ptr(dev))
-            _lib.check(rc, "u3d_rasterize_backward")
-        return (g_means3D, g_means2D, g_shs, g_col if colors_precomp is not None else None, g_op, g_scales, g_rot, g_cov,
-                None, None, None, None, None, None, None, None, None, None, None, None, None)
+def _C():
+    """The torch binding of the operator (csrc/u3d_torch.cpp): a C++ autograd function over the C-ABI -- what the third-party
+    package's `_C` module is to its Python wrapper.  The reference calls the operator once per object and view
+    (train_network.py:418-446), so the per-call host cost decides that route: ~25 us per forward+backward pair here against
+    ~200 us for an autograd.Function written in Python over ctypes.  No fallback: a missing binding raises."""
+    global _binding
+    if _binding is None:
+        _lib.load()          # the C-ABI library the binding links against (and `import torch` before either)
+        if not os.path.exists(_BINDING_PATH):
+            raise RuntimeError(f"{_BINDING_PATH} is missing: the MI355X rasterizer has no fallback path. Build it with "
+                               "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C unipre3d_amd/csrc`.")
+        import importlib.machinery
+        import importlib.util
+        spec = importlib.util.spec_from_loader("_u3d_torch", importlib.machinery.ExtensionFileLoader("_u3d_torch", _BINDING_PATH))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if mod.abi_version() != _lib.ABI_VERSION:
+            raise RuntimeError("_u3d_torch.so was built against another ABI version of libunipre3d_rasterizer.so; rebuild")
+        _binding = mod
+    return _binding
 
 
 def _flags(settings: GaussianRasterizationSettings, exact_aa_grad: bool = False) -> int:
@@ -163,20 +123,11 @@ def _flags(settings: GaussianRasterizationSettings, exact_aa_grad: bool = False)
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings: GaussianRasterizationSettings, exact_aa_grad: bool = False):
     """One view (the reference's operator).  Shapes: means3D (P,3), means2D (P,3), sh (P,M,3) | colors (P,3),
-    opacities (P,1), scales (P,3), rotations (P,4) | cov3D (P,6)."""
+    opacities (P,1), scales (P,3), rotations (P,4) | cov3D (P,6).  Empty tensors count as absent (upstream's convention)."""
     s = raster_settings
-    dev = means3D.device
-    sh, colors_precomp = _none_if_empty(sh), _none_if_empty(colors_precomp)
-    scales, rotations, cov3Ds_precomp = _none_if_empty(scales), _none_if_empty(rotations), _none_if_empty(cov3Ds_precomp)
-    P = means3D.shape[0]
-    un = lambda t: None if t is None else _f32c(t, dev).unsqueeze(0)
-    color, radii, invdepth = _RasterizeFn.apply(
-        un(means3D), un(means2D if means2D is not None else torch.zeros_like(means3D)), un(sh), un(colors_precomp),
-        un(opacities.reshape(P, 1)), un(scales), un(rotations), un(cov3Ds_precomp), _f32c(s.viewmatrix, dev).reshape(1, 16),
-        _f32c(s.projmatrix, dev).reshape(1, 16), _f32c(s.campos, dev).reshape(1, 3), _f32c(s.bg, dev).reshape(3), 1, 1,
-        int(s.image_height), int(s.image_width), float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier),
-        int(s.sh_degree), _flags(s, exact_aa_grad))
-    return color[0], radii[0], invdepth[0]
+    return _C().rasterize_view(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, s.viewmatrix,
+                               s.projmatrix, s.campos, s.bg, int(s.image_height), int(s.image_width), float(s.tanfovx), float(s.tanfovy),
+                               float(s.scale_modifier), int(s.sh_degree), _flags(s, exact_aa_grad))
 
 
 def rasterize_gaussians_batched(means3D, opacities, viewmatrix, projmatrix, campos, bg, image_height, image_width, tanfovx,
@@ -195,17 +146,17 @@ def rasterize_gaussians_batched(means3D, opacities, viewmatrix, projmatrix, camp
             ((scales is not None or rotations is not None) and cov3D_precomp is not None):
         raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
     dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback "
+                           "(the CPU restatement lives in oracle/ and is test infrastructure only)")
     B, P = means3D.shape[0], means3D.shape[1]
     V = viewmatrix.shape[1]
     flags = (_lib.FLAG_ANTIALIASING if antialiasing else 0) | (_lib.FLAG_DEBUG if debug else 0) | \
         (_lib.FLAG_EXACT_AA_GRAD if exact_aa_grad else 0)
-    f = lambda t: _f32c(t, dev)
-    color, radii, invdepth = _RasterizeFn.apply(
-        f(means3D), means2D if means2D is not None else torch.zeros(B * V, P, 3, device=dev), f(shs), f(colors_precomp),
-        f(opacities).reshape(B, P, 1), f(scales),
-        f(rotations), f(cov3D_precomp), f(viewmatrix).reshape(B * V, 16), f(projmatrix).reshape(B * V, 16),
-        f(campos).reshape(B * V, 3), f(bg).reshape(3), B, V, int(image_height), int(image_width), float(tanfovx),
-        float(tanfovy), float(scale_modifier), int(sh_degree), flags)
+    color, radii, invdepth = _C().rasterize_batched(
+        means3D, means2D, shs, colors_precomp, opacities.reshape(B, P, 1), scales, rotations, cov3D_precomp,
+        viewmatrix.reshape(B * V, 16), projmatrix.reshape(B * V, 16), campos.reshape(B * V, 3), bg.reshape(3), B, V, int(image_height),
+        int(image_width), float(tanfovx), float(tanfovy), float(scale_modifier), int(sh_degree), flags)
     return (color.reshape(B, V, 3, image_height, image_width), radii.reshape(B, V, P),
             invdepth.reshape(B, V, 1, image_height, image_width))
 
