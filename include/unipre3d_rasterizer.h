@@ -45,12 +45,13 @@ extern "C" {
 #define U3D_FLAG_EXACT_AA_GRAD 8 /* exact derivative of the anti-aliasing factor (DEV(vi)) */
 #define U3D_FLAG_STATS 16        /* also accumulate num_rendered[view] = sum of tiles touched (same-address atomics:
                                     ~12 ns each, 0.25 ms at 1.6 M Gaussian-views -- statistics only, off by default) */
-#define U3D_FLAG_ACC_CLEAN 32    /* u3d_render_loss_step only: the caller guarantees that the gradient accumulators at the start of
-                                    `backward_scratch` (the first acc_bytes) are all zero on entry -- because it zeroed them once, or
-                                    because the previous call that used this scratch was a u3d_render_loss_step WITH THE SAME
-                                    DESCRIPTOR SHAPE that returned U3D_OK (every such call leaves them zero again; another shape
-                                    lays the scratch out differently).  The step then skips clearing 80 bytes per
-                                    (view, Gaussian) pair, most of its projection kernel's traffic at scene level */
+#define U3D_FLAG_ACC_CLEAN 32    /* u3d_render_loss_step and u3d_rasterize_backward: the caller guarantees that the gradient accumulators
+                                    at the start of `backward_scratch` (the first acc_bytes) are all zero on entry -- because it zeroed
+                                    them once, or because the previous call that used this scratch was one of these two entry points
+                                    WITH THE SAME DESCRIPTOR SHAPE that returned U3D_OK (every such call leaves them zero again; another
+                                    shape lays the scratch out differently).  The call then skips clearing 80 bytes per (view,
+                                    Gaussian) pair: most of the step's projection-kernel traffic at scene level, one launch per call of
+                                    the per-view operator route */
 
 #define U3D_OK 0
 #define U3D_ERR_INVALID_ARGUMENT 1
@@ -136,7 +137,8 @@ int u3d_rasterize_forward(const u3d_raster_desc* desc, const float* bg, const fl
  *   dL_dcov3D [n_items][P][6] (may be NULL),
  *   dL_dmeans2D [n_views][P][3] (may be NULL): screen-space gradient, the `viewspace_points` sink of
  *                                               gaussian_renderer/__init__.py:29.
- *   backward_scratch: backward_bytes; zeroed by the call.
+ *   backward_scratch: backward_bytes; the call clears its accumulators first unless U3D_FLAG_ACC_CLEAN vouches for them, and
+ *                     always hands them back zero.
  */
 int u3d_rasterize_backward(const u3d_raster_desc* desc, const float* bg, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,

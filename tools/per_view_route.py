@@ -1,16 +1,26 @@
-"""The unmodified reference loop (one operator call per object and view, train_network.py:418-446) against the batched routes, C2."""
-import sys, os, time, types, torch
+"""The unmodified reference loop (one operator call per object and view, train_network.py:418-446) through the drop-in module at
+C2, and the same loop with a NO-OP operator (allocates its outputs, launches nothing): what the wrapper around the operator costs
+by itself -- render_predicted's zeros_like / cat / radii>0, the per-item slicing, torch.stack, the loss, and autograd's backward
+through all of them (~14 small kernels per view).  Usage: python tools/per_view_route.py [steps]"""
+import os
+import sys
+import time
+import types
+
+import torch
+
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from unipre3d_amd import synthetic, renderer, losses, fused
+from unipre3d_amd import head, losses, rasterizer, renderer, synthetic  # noqa: E402
+
 dev = torch.device("cuda")
 cfgc = synthetic.CONFIGS["C2"]; B, P, V, H, W = cfgc["B"], cfgc["P"], cfgc["V"], cfgc["H"], cfgc["W"]
 b = synthetic.make_batch(B, P, V, H, W, seed=42).to(dev)
 cfg = types.SimpleNamespace(data=types.SimpleNamespace(fov=b.fov_deg, training_resolution=H), model=types.SimpleNamespace(max_sh_degree=1))
 raw = b.raw.clone().requires_grad_(True)
 
+
 def per_view_step():
     raw.grad = None
-    from unipre3d_amd import head
     gs = head.process_object_output(raw, b.center, b.offset_scale)
     imgs = []
     for i in range(B):
@@ -22,10 +32,37 @@ def per_view_step():
     loss.backward()
     return loss
 
-for name, fn, n in (("per-view operator loop (reference call pattern)", per_view_step, 5),):
-    fn(); torch.cuda.synchronize()
+
+class _NullOp(torch.autograd.Function):
+    """Same inputs / outputs as the operator, no kernel: outputs and gradients are uninitialised allocations."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, opacities, scales, rotations):
+        ctx.shapes = [t.shape for t in (means3D, means2D, shs, opacities, scales, rotations)]
+        ctx.dev = means3D.device
+        return torch.empty(3, H, W, device=means3D.device), torch.empty(P, dtype=torch.int32, device=means3D.device)
+
+    @staticmethod
+    def backward(ctx, g, _):
+        return tuple(torch.empty(s, device=ctx.dev) for s in ctx.shapes)
+
+
+def timeit(name, fn, n):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(n): l = fn()
+    for _ in range(n):
+        l = fn()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / n
-    print("%-50s %.2f ms/step  %.0f views/s  loss %.6f" % (name, ms, B * V / ms * 1e3, float(l)))
+    print("%-58s %.2f ms/step  %.0f views/s  %.0f us per forward+backward pair" % (name, ms, B * V / ms * 1e3, 1e3 * ms / (B * V)))
+
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+timeit("per-view operator loop (reference call pattern)", per_view_step, n)
+real = rasterizer.GaussianRasterizer.forward
+rasterizer.GaussianRasterizer.forward = lambda self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None: \
+    _NullOp.apply(means3D, means2D, shs, opacities, scales, rotations) + (None,)
+timeit("same loop, NO-OP operator (the wrapper's own cost)", per_view_step, n)
+rasterizer.GaussianRasterizer.forward = real

@@ -224,7 +224,10 @@ int u3d_rasterize_backward(const u3d_raster_desc* desc, const float* bg, const f
   const U3DLayout L = u3d_carve(d, (void*)geom, (void*)binning, (void*)image, &b);
   double* acc = (double*)backward_scratch;
   float* part = (float*)((char*)backward_scratch + L.acc_bytes);
-  (void)hipMemsetAsync(acc, 0, L.acc_bytes, s);
+  // U3D_FLAG_ACC_CLEAN: the caller keeps this scratch between calls of this shape and vouches that the accumulators are zero
+  // (the previous call handed them back zeroed, see below): no memset node -- one launch less per call of the per-view route
+  const bool clean = (d.flags & U3D_FLAG_ACC_CLEAN) != 0;
+  if (!clean) (void)hipMemsetAsync(acc, 0, L.acc_bytes, s);
   {
     ProfScope ps(3, s);
     u3d_launch_render_bwd(d, b, bg, dL_dcolor, dL_dinvdepth, nullptr, U3DLoss{}, acc, part, s);
@@ -235,8 +238,9 @@ int u3d_rasterize_backward(const u3d_raster_desc* desc, const float* bg, const f
     sink.means = dL_dmeans3D; sink.shs = shs ? dL_dshs : nullptr; sink.colors = dL_dcolors; sink.opac = dL_dopacity;
     sink.scales = scales ? dL_dscales : nullptr; sink.rots = scales ? dL_drotations : nullptr; sink.cov = dL_dcov3D;
     sink.means2D = dL_dmeans2D; sink.qdot = nullptr;
+    // (always hands the accumulators it read back zeroed: only the touched (view, Gaussian) pairs were ever written)
     u3d_launch_preprocess_bwd(d, b, plain_source(d, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp),
-                              viewmatrix, projmatrix, campos, radii, acc, sink, s);
+                              viewmatrix, projmatrix, campos, radii, acc, sink, s, acc);
   }
   return finish(desc, s);
 }

@@ -12,7 +12,9 @@
 
 #include <array>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <unordered_map>
 
 #include "unipre3d_rasterizer.h"
@@ -50,6 +52,32 @@ const Plan& plan_for(const u3d_raster_desc& d) {
   return cache.emplace(std::move(key), p).first->second;
 }
 
+// Backward scratch kept per (device, stream, shape): a backward call leaves its gradient accumulators zero, so the next call on
+// the same stream with the same shape is told not to clear them again (U3D_FLAG_ACC_CLEAN) -- no allocation and one launch less
+// per call.  Calls on one stream are ordered, so one scratch per stream is enough; `clean` is dropped while a call is in flight on
+// the host so that a failed call cannot leave a stale promise behind.
+struct Workspace { Tensor buf; bool clean = false; };
+using WsKey = std::tuple<int, void*, const Plan*>;
+std::mutex g_ws_mu;
+std::map<WsKey, Workspace> g_ws;
+// takes the scratch of `key` (allocating it on first use) and withdraws its promise; returns whether the promise held
+std::pair<Tensor, bool> workspace_acquire(const WsKey& key, const at::TensorOptions& byte_opts) {
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  auto it = g_ws.find(key);
+  if (it == g_ws.end()) {
+    if (g_ws.size() >= 16) g_ws.clear();      // shapes come and go (validation sizes, ragged scenes): keep the cache small
+    it = g_ws.emplace(key, Workspace{at::empty({(int64_t)std::get<2>(key)->s.backward_bytes}, byte_opts), false}).first;
+  }
+  const bool clean = it->second.clean;
+  it->second.clean = false;
+  return {it->second.buf, clean};
+}
+void workspace_release(const WsKey& key, const Tensor& buf) {   // the call succeeded: its accumulators are zero again
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  auto it = g_ws.find(key);
+  if (it != g_ws.end() && it->second.buf.is_same(buf)) it->second.clean = true;
+}
+
 inline const float* fptr(const Tensor& t) { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; }
 inline float* fptr_mut(Tensor& t) { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; }
 
@@ -82,6 +110,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                                "(the CPU restatement lives in oracle/ and is test infrastructure only)");
     auto val = [](const OptTensor& t) { return t.has_value() ? *t : Tensor(); };
     const Tensor shs = val(shs_), colors = val(colors_), scales = val(scales_), rots = val(rots_), cov = val(cov_);
+    // (means2D carries no data forward: it is the gradient sink `viewspace_points` of gaussian_renderer/__init__.py:29)
     const int64_t P = means3D.numel() > 0 ? means3D.size(-2) : 0;
     const int64_t M = shs.defined() ? shs.size(-2) : 0;
     u3d_raster_desc d{};
@@ -106,6 +135,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     ctx->saved_data["plan"] = (int64_t)(intptr_t)&plan;      // (cache entries are never moved: unordered_map nodes are stable)
     ctx->saved_data["has_colors"] = colors.defined();
     ctx->saved_data["single"] = single;
+    ctx->saved_data["has_means2D"] = means2D_.has_value() && means2D_->defined();
     ctx->save_for_backward({means3D, shs, colors, opac, scales, rots, cov, view, proj, campos, bg, radii, arena});
     ctx->mark_non_differentiable({radii});
     ctx->set_materialize_grads(false);    // unused outputs (invdepth) arrive undefined, not as a zero tensor
@@ -116,6 +146,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     const Plan& plan = *(const Plan*)(intptr_t)ctx->saved_data["plan"].toInt();
     const bool has_colors = ctx->saved_data["has_colors"].toBool();
     const bool single = ctx->saved_data["single"].toBool();
+    const bool has_m2d = ctx->saved_data["has_means2D"].toBool();
     auto sv = ctx->get_saved_variables();
     const Tensor &means3D = sv[0], &shs = sv[1], &colors = sv[2], &opac = sv[3], &scales = sv[4], &rots = sv[5], &cov = sv[6], &view = sv[7],
                  &proj = sv[8], &campos = sv[9], &bg = sv[10], &radii = sv[11], &arena = sv[12];
@@ -133,21 +164,26 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
       std::vector<int64_t> sh(shape.begin() + (single ? 1 : 0), shape.end());     // single: drop the leading set / view dimension
       return live ? at::empty(sh, fopt) : at::zeros(sh, fopt);
     };
-    Tensor g_means3D = out({n, P, 3}), g_means2D = out({NV, P, 3}), g_op = out({n, P, 1});
+    Tensor g_means3D = out({n, P, 3}), g_means2D = has_m2d ? out({NV, P, 3}) : Tensor(), g_op = out({n, P, 1});
     Tensor g_shs = shs.defined() ? out({n, P, M, 3}) : Tensor();
     Tensor g_col = has_colors ? out({n, P, 3}) : Tensor();
     Tensor g_scales = scales.defined() ? out({n, P, 3}) : Tensor();
     Tensor g_rots = scales.defined() ? out({n, P, 4}) : Tensor();
     Tensor g_cov = cov.defined() ? out({n, P, 6}) : Tensor();
     if (live) {
-      Tensor scratch = at::empty({(int64_t)plan.s.backward_bytes}, fopt.dtype(at::kByte));
+      void* stream = current_stream(dev);
+      const WsKey key{(int)dev.index(), stream, &plan};
+      auto [scratch, clean] = workspace_acquire(key, fopt.dtype(at::kByte));
+      u3d_raster_desc dd = plan.d;
+      if (clean) dd.flags |= U3D_FLAG_ACC_CLEAN;
       const char* base = (const char*)arena.data_ptr();
-      const int rc = u3d_rasterize_backward(&plan.d, fptr(bg), fptr(means3D), fptr(shs), fptr(colors), fptr(opac), fptr(scales), fptr(rots),
+      const int rc = u3d_rasterize_backward(&dd, fptr(bg), fptr(means3D), fptr(shs), fptr(colors), fptr(opac), fptr(scales), fptr(rots),
                                             fptr(cov), fptr(view), fptr(proj), fptr(campos), radii.data_ptr<int32_t>(), fptr(gcol), fptr(ginv),
                                             base, base + plan.o_binning, base + plan.o_image, scratch.data_ptr(), fptr_mut(g_means3D),
                                             fptr_mut(g_means2D), fptr_mut(g_shs), fptr_mut(g_col), fptr_mut(g_op), fptr_mut(g_scales),
-                                            fptr_mut(g_rots), fptr_mut(g_cov), current_stream(dev));
+                                            fptr_mut(g_rots), fptr_mut(g_cov), stream);
       TORCH_CHECK(rc == U3D_OK, "u3d_rasterize_backward failed: ", u3d_error_string(rc), " (code ", rc, ")");
+      workspace_release(key, scratch);
     }
     return {g_means3D, g_means2D, g_shs, g_col, g_op, g_scales, g_rots, g_cov, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
             Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
@@ -197,4 +233,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize_view", &rasterize_view, "one view: the reference's per-view operator call");
   m.def("rasterize_batched", &rasterize_batched, "n_items sets x views_per_item cameras in one launch sequence");
   m.def("abi_version", []() { return u3d_abi_version(); });
+  m.def("clear_workspaces", []() { std::lock_guard<std::mutex> lock(g_ws_mu); g_ws.clear(); },
+        "drop the cached backward scratch buffers (the next backward of every shape clears its accumulators itself)");
+  m.def("workspaces", []() { std::lock_guard<std::mutex> lock(g_ws_mu); int n = 0, c = 0; for (auto& kv : g_ws) { ++n; c += kv.second.clean; } return std::make_pair(n, c); },
+        "(cached backward scratch buffers, how many of them hold the accumulators-are-zero promise)");
 }
