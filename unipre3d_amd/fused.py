@@ -191,7 +191,8 @@ def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: 
                                        1 if level == "object" else 2, float(offset_scale), int(max_sh_degree), loss_kind,
                                        float(non_bg_color_loss_rate), float(bg_color_loss_rate), float(scaling_modifier), flags,
                                        bool(return_images))
-    return _RenderLossFn.apply(f(head_out), f(center), f(wv).reshape(NV, 16), f(fp).reshape(NV, 16), f(cc).reshape(NV, 3),
-                               f(gt[:, input_images:]).reshape(NV, 3, H, W), f(bg).reshape(3), int(H), int(W), float(t),
-                               1 if level == "object" else 2, float(offset_scale), int(max_sh_degree), loss_kind,
-                               float(non_bg_color_loss_rate), float(bg_color_loss_rate), float(scaling_modifier), flags)
+    loss, img, radii = _RenderLossFn.apply(f(head_out), f(center), f(wv).reshape(NV, 16), f(fp).reshape(NV, 16), f(cc).reshape(NV, 3),
+                                           f(gt[:, input_images:]).reshape(NV, 3, H, W), f(bg).reshape(3), int(H), int(W), float(t),
+                                           1 if level == "object" else 2, float(offset_scale), int(max_sh_degree), loss_kind,
+                                           float(non_bg_color_loss_rate), float(bg_color_loss_rate), float(scaling_modifier), flags)
+    return loss, (img if differentiable_images else img.detach()), radii
