@@ -311,3 +311,24 @@ def test_loop_variant_selection(oracle_mod):
     sc3["scales"][first] = torch.tensor([20.0, 1e-3, 1e-3])
     (last3, plain3), _ = flags(sc3)
     assert not plain3.all()
+
+
+def test_g8_analytic_known_answers(golden):
+    """The HIP operator against closed-form answers that were derived without the oracle (tests/golden/make_g8_analytic.py)."""
+    from g8_cases import run_g8
+    from unipre3d_amd.rasterizer import GaussianRasterizationSettings, rasterize_gaussians
+    dev = torch.device("cuda:0")
+
+    def render(means, scales, rots, opac, shs, view, proj, campos, bg, S, t, deg, aa, dcol):
+        T = lambda a, grad=False: torch.tensor(np.asarray(a, dtype=np.float32), device=dev).requires_grad_(grad)
+        m, s, q, o, sh = T(means, True), T(scales, True), T(rots, True), T(opac, True), T(shs, True)
+        st = GaussianRasterizationSettings(S, S, t, t, T(bg), 1.0, T(view), T(proj), deg, T(campos), False, True, aa)
+        color, radii, _ = rasterize_gaussians(m, torch.zeros_like(m), sh, None, o, s, q, None, st)
+        gr = None
+        if dcol is not None:
+            (color * T(dcol)).sum().backward()
+            gr = {"means3D": m.grad.cpu().numpy(), "scales": s.grad.cpu().numpy(), "opacities": o.grad.cpu().numpy(), "shs": sh.grad.cpu().numpy()}
+        return color.detach().cpu().numpy(), radii.cpu().numpy(), gr
+
+    rep = run_g8(golden("g8_analytic.npz"), render)
+    print("g8 analytic:", {k: f"{v:.1e}" for k, v in rep.items()})
