@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define U3D_ABI_VERSION 2
+#define U3D_ABI_VERSION 3
 
 /* flags (fields 11-13 of GaussianRasterizationSettings, gaussian_renderer/__init__.py:56-58) */
 #define U3D_FLAG_PREFILTERED 1   /* accepted, no effect: culled points are dropped either way */
@@ -62,7 +62,7 @@ extern "C" {
 typedef struct u3d_raster_desc {
   int32_t n_items;        /* independent Gaussian sets (objects / scenes) in this call, <= 65535 */
   int32_t views_per_item; /* cameras per set; n_views = n_items * views_per_item               */
-  int32_t P;              /* Gaussians per set                                                 */
+  int32_t P;              /* Gaussians per set (uniform batch); the LARGEST set of a ragged batch */
   int32_t image_height;   /* settings field 1                                                  */
   int32_t image_width;    /* settings field 2                                                  */
   float tanfovx;          /* settings field 3                                                  */
@@ -71,6 +71,13 @@ typedef struct u3d_raster_desc {
   int32_t sh_degree;      /* settings field 9: active SH degree D in 0..3                      */
   int32_t sh_coeffs;      /* M = shs.shape[1] >= (D+1)^2; 0 when colors_precomp is used        */
   int32_t flags;          /* U3D_FLAG_*                                                        */
+  /* Ragged batches -- the reference's scene-level branch returns python LISTS of per-item (M_i, .) tensors
+     (model/gaussian_predictor.py:331-364).  total_P == 0: every set has exactly P Gaussians (the layouts documented below).
+     total_P > 0: set i has item_offsets[i+1] - item_offsets[i] Gaussians (at most P); every per-Gaussian input and gradient is
+     PACKED, [total_P][...] in set order; per-(view, Gaussian) outputs (radii, dL_dmeans2D) are packed
+     [views_per_item * total_P] with the pairs of set i, view v at  views_per_item * item_offsets[i] + v * P_i . */
+  int32_t total_P;
+  const int32_t* item_offsets; /* DEVICE pointer to n_items + 1 prefix sums (first 0, last total_P); NULL iff total_P == 0 */
 } u3d_raster_desc;
 
 typedef struct u3d_scratch_sizes {
@@ -89,6 +96,8 @@ typedef struct u3d_head_desc {
                           F.normalize on (B,4,N), :254,:318), 2 = scene level (per quaternion, :347-349) */
   int32_t channels;    /* C = 11 + 3*(D+1)^2: xyz 3 | opacity 1 | scaling 3 | rotation 4 | SH 3*(D+1)^2 */
   float offset_scale;  /* cfg.model.offset_scale                                                         */
+  int32_t isotropic;   /* cfg.model.isotropic (model/gaussian_predictor.py:308-310): the first scaling channel is used for all
+                          three axes; the other two channels receive zero gradient                        */
 } u3d_head_desc;
 
 /* Render loss fused into the rasterizer (utils/loss_utils.py:17-45 via train_network.py:260-302). */

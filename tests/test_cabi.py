@@ -28,15 +28,18 @@ def test_every_declared_symbol_is_exported(lib):
     assert set(names) == set(_lib.EXPORTS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.u3d_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.u3d_abi_version() == _lib.ABI_VERSION == 3
     assert lib.u3d_error_string(0) == b"ok" and b"invalid" in lib.u3d_error_string(1)
 
 
 def test_header_and_ctypes_struct_agree():
     hdr = open(os.path.join(ROOT, "include", "unipre3d_rasterizer.h")).read()
     body = re.search(r"typedef struct u3d_raster_desc \{(.*?)\} u3d_raster_desc;", hdr, re.S).group(1)
-    fields = re.findall(r"^\s*(?:int32_t|float)\s+(\w+);", body, re.M)
+    fields = re.findall(r"^\s*(?:int32_t|float|const int32_t\*)\s+(\w+);", body, re.M)
     assert fields == [f[0] for f in _lib.RasterDesc._fields_]
+    assert ctypes.sizeof(_lib.RasterDesc) == 56 and _lib.RasterDesc.item_offsets.offset == 48      # 12 x 4 bytes, then the pointer
+    body = re.search(r"typedef struct u3d_head_desc \{(.*?)\} u3d_head_desc;", hdr, re.S).group(1)
+    assert re.findall(r"^\s*(?:int32_t|float)\s+(\w+);", body, re.M) == [f[0] for f in _lib.HeadDesc._fields_]
     body = re.search(r"typedef struct u3d_scratch_sizes \{(.*?)\} u3d_scratch_sizes;", hdr, re.S).group(1)
     fields = re.findall(r"^\s*size_t\s+(\w+);", body, re.M)
     assert fields == [f[0] for f in _lib.ScratchSizes._fields_]

@@ -1,0 +1,151 @@
+"""Ragged batches -- the reference's scene-level branch returns per-item LISTS of (M_i, .) tensors
+(model/gaussian_predictor.py:331-364): sets of different sizes in ONE launch sequence (u3d_raster_desc.total_P / item_offsets)
+must equal one call per set.  Also cfg.model.isotropic (:308-310) through the fused route."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+KEYS = ("xyz", "opacity", "scaling", "rotation")
+
+
+def _sets(sizes, V, H, W, level, seed):
+    from unipre3d_amd import synthetic
+    dev = torch.device("cuda:0")
+    out = []
+    for k, n in enumerate(sizes):
+        b = synthetic.make_batch(1, n, V, H, W, level=level, seed=seed + k).to(dev)
+        out.append(b)
+    return out
+
+
+@pytest.mark.parametrize("sizes,level", [((100, 37, 256), "object"), ((300, 2048, 1000), "scene"), ((700, 5000, 1, 4200), "scene")])
+def test_ragged_operator_equals_one_call_per_set(sizes, level):
+    """Covers the three sort routes (largest set <= 256: fused into the projection kernel; <= 4096: one-workgroup LDS sort;
+    beyond: bucketed), sets shorter than a workgroup's span, and a one-Gaussian set."""
+    from unipre3d_amd import head, synthetic
+    from unipre3d_amd.rasterizer import pack_ragged, rasterize_gaussians_batched, split_ragged_radii
+    V, H, W = 2, 64, 80
+    bs = _sets(sizes, V, H, W, level, 40)
+    t = math.tan(bs[0].fov_deg * math.pi / 360)
+    gs = [{k: v[0].detach().clone().requires_grad_(True) for k, v in synthetic.gaussians_from_batch(b).items()} for b in bs]
+    cot = torch.randn(len(sizes), V, 3, H, W, generator=torch.Generator().manual_seed(2)).cuda()
+    # one call per set
+    ref = []
+    for i, (b, g) in enumerate(zip(bs, gs)):
+        shs = head.concat_sh(g["features_dc"], g["features_rest"])
+        shs.retain_grad()
+        m2d = torch.zeros(V, sizes[i], 3, device="cuda", requires_grad=True)
+        col, radii, inv = rasterize_gaussians_batched(g["xyz"][None], g["opacity"][None], b.world_view, b.full_proj, b.camera_center, b.bg, H, W, t, t,
+                                                      shs=shs[None], scales=g["scaling"][None], rotations=g["rotation"][None], sh_degree=1, means2D=m2d)
+        (col * cot[i]).sum().backward()
+        ref.append((col.detach(), radii, inv.detach(), {k: g[k].grad.clone() for k in KEYS}, shs.grad.clone(), m2d.grad.clone()))
+        for k in KEYS:
+            g[k].grad = None
+    # the same sets packed into ONE launch sequence
+    packed = {k: pack_ragged([g[k] for g in gs]) for k in KEYS}
+    off, szs = packed["xyz"][1], packed["xyz"][2]
+    shs_p = torch.cat([head.concat_sh(g["features_dc"], g["features_rest"]) for g in gs])
+    shs_p.retain_grad()
+    m2d_p = torch.zeros(V * sum(sizes), 3, device="cuda", requires_grad=True)
+    wv, fp, cc = (torch.cat([getattr(b, n) for b in bs]) for n in ("world_view", "full_proj", "camera_center"))
+    col, radii, inv = rasterize_gaussians_batched(packed["xyz"][0], packed["opacity"][0], wv, fp, cc, bs[0].bg, H, W, t, t, shs=shs_p,
+                                                  scales=packed["scaling"][0], rotations=packed["rotation"][0], sh_degree=1, means2D=m2d_p,
+                                                  item_offsets=off, max_P=max(sizes), debug=True)
+    (col * cot).sum().backward()
+    torch.cuda.synchronize()
+    r_list, m_list = split_ragged_radii(radii, szs, V), split_ragged_radii(m2d_p.grad, szs, V)
+    o = 0
+    for i, n in enumerate(sizes):
+        assert torch.equal(col[i], ref[i][0][0]) and torch.equal(inv[i], ref[i][2][0]), i      # same forward arithmetic
+        assert torch.equal(r_list[i], ref[i][1][0]), i
+        for k in KEYS:       # (the cross-slice f64 atomics of the gradient reduction are order-insensitive, not bit-identical)
+            a, b_ = gs[i][k].grad, ref[i][3][k]
+            assert rel_l2(a.cpu().numpy(), b_.cpu().numpy()) < 1e-6 if b_.abs().sum() > 0 else not a.any(), (i, k)
+        assert rel_l2(shs_p.grad[o:o + n].cpu().numpy(), ref[i][4].cpu().numpy()) < 1e-6
+        assert rel_l2(m_list[i].cpu().numpy(), ref[i][5].cpu().numpy()) < 1e-6
+        o += n
+
+
+@pytest.mark.parametrize("sizes,level,kind", [((128, 60, 200), "object", "focal_l2"), ((900, 5000, 2500), "scene", "l2")])
+@pytest.mark.parametrize("single_pass", [True, False])
+def test_ragged_fused_step_equals_one_call_per_set(sizes, level, kind, single_pass):
+    from unipre3d_amd import fused
+    from unipre3d_amd.rasterizer import pack_ragged
+    V, H, W = 3, 48, 64
+    bs = _sets(sizes, V, H, W, level, 60)
+    B = len(sizes)
+    ref_loss, ref_grad, ref_img = [], [], []
+    for b in bs:
+        h = b.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+        loss, img, _ = fused.render_loss_fused(h, b.center, b.world_view, b.full_proj, b.camera_center, b.gt, b.bg, b.fov_deg, H, W, level=level,
+                                               offset_scale=b.offset_scale, loss_kind=kind, single_pass=single_pass)
+        loss.backward()
+        ref_loss.append(loss.item()); ref_grad.append(h.grad[0].clone()); ref_img.append(img)
+    hp, off, szs = pack_ragged([b.raw[0].t().contiguous() for b in bs])
+    hp = hp.detach().requires_grad_(True)
+    cp = torch.cat([b.center[0] for b in bs])
+    wv, fp, cc, gt = (torch.cat([getattr(b, n) for b in bs]) for n in ("world_view", "full_proj", "camera_center", "gt"))
+    for rnd in range(2):                                     # the second round runs with U3D_FLAG_ACC_CLEAN on the kept workspace
+        hp.grad = None
+        loss, img, radii = fused.render_loss_fused(hp, cp, wv, fp, cc, gt, bs[0].bg, bs[0].fov_deg, H, W, level=level, offset_scale=bs[0].offset_scale,
+                                                   loss_kind=kind, single_pass=single_pass, item_offsets=off, max_P=max(sizes), debug=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(loss.item() - sum(ref_loss) / B) <= 1e-6 * abs(loss.item())
+        assert radii.shape == (V * sum(sizes),)
+        o = 0
+        for i, n in enumerate(sizes):
+            assert torch.equal(img[i * V:(i + 1) * V], ref_img[i]), (rnd, i)
+            a, b_ = hp.grad[o:o + n] * B, ref_grad[i]            # the packed loss averages over B times as many pixels
+            assert rel_l2(a.cpu().numpy(), b_.cpu().numpy()) < 2e-6, (rnd, i, rel_l2(a.cpu().numpy(), b_.cpu().numpy()))
+            o += n
+
+
+def test_ragged_argument_errors():
+    from unipre3d_amd import _lib, fused
+    import ctypes
+    lib = _lib.load()
+    sizes = _lib.ScratchSizes()
+    d = _lib.RasterDesc(2, 1, 100, 32, 32, 0.5, 0.5, 1.0, 1, 4, 2)
+    d.total_P = 150                                          # ragged without prefix sums
+    assert lib.u3d_scratch_query(ctypes.byref(d), ctypes.byref(sizes)) == 1
+    d.item_offsets = 8
+    assert lib.u3d_scratch_query(ctypes.byref(d), ctypes.byref(sizes)) == 0
+    d.total_P = 250                                          # more than n_items * largest set
+    assert lib.u3d_scratch_query(ctypes.byref(d), ctypes.byref(sizes)) == 1
+    d.total_P = 50                                           # less than the largest set
+    assert lib.u3d_scratch_query(ctypes.byref(d), ctypes.byref(sizes)) == 1
+    h = torch.zeros(10, 23, device="cuda", requires_grad=True)
+    with pytest.raises(ValueError):
+        fused._batch_shape(h, torch.zeros(3, dtype=torch.int64, device="cuda"), 5)
+    with pytest.raises(ValueError):
+        fused._batch_shape(h, torch.zeros(3, dtype=torch.int32, device="cuda"), 0)
+
+
+@pytest.mark.parametrize("single_pass", [True, False])
+def test_isotropic_head_variant(single_pass):
+    """cfg.model.isotropic (model/gaussian_predictor.py:308-310): scaling[:, :1].expand(-1, 3, -1) -- the first scaling channel
+    serves all three axes and receives the three gradients, the other two channels receive none."""
+    from unipre3d_amd import fused, head, losses, renderer, synthetic
+    dev = torch.device("cuda:0")
+    b = synthetic.make_batch(2, 128, 3, 64, 64, seed=15).to(dev)
+    h = b.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+    loss, img, _ = fused.render_loss_fused(h, b.center, b.world_view, b.full_proj, b.camera_center, b.gt, b.bg, b.fov_deg, 64, 64,
+                                           loss_kind="focal_l2", single_pass=single_pass, isotropic=True, debug=True)
+    loss.backward()
+    raw = b.raw.clone().requires_grad_(True)
+    g = head.process_object_output(raw, b.center, 1.0, 1, isotropic=True)
+    out = renderer.render_views(g, b.world_view, b.full_proj, b.camera_center, b.bg, b.fov_deg, 64, 64)
+    lu = losses.render_loss(out, b.gt.reshape(-1, 3, 64, 64), "focal_l2")
+    lu.backward()
+    assert rel_l2(img.cpu().numpy(), out.detach().cpu().numpy()) < 1e-5 and abs(loss.item() - lu.item()) < 1e-6
+    assert rel_l2(h.grad.cpu().numpy(), raw.grad.permute(0, 2, 1).cpu().numpy()) < 1e-4
+    assert not h.grad[..., 5:7].any() and h.grad[..., 4].abs().sum() > 0
+    # and it is a different render from the anisotropic one
+    _, img_a, _ = fused.render_loss_fused(h.detach(), b.center, b.world_view, b.full_proj, b.camera_center, b.gt, b.bg, b.fov_deg, 64, 64)
+    assert rel_l2(img.cpu().numpy(), img_a.cpu().numpy()) > 1e-2

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libunipre3d_rasterizer.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 2   # include/unipre3d_rasterizer.h: U3D_ABI_VERSION
+ABI_VERSION = 3   # include/unipre3d_rasterizer.h: U3D_ABI_VERSION
 FLAG_PREFILTERED, FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_EXACT_AA_GRAD, FLAG_STATS, FLAG_ACC_CLEAN = 1, 2, 4, 8, 16, 32
 
 EXPORTS = ("u3d_abi_version", "u3d_error_string", "u3d_scratch_query", "u3d_rasterize_forward",
@@ -30,7 +30,9 @@ class RasterDesc(ctypes.Structure):
     _fields_ = [("n_items", ctypes.c_int32), ("views_per_item", ctypes.c_int32), ("P", ctypes.c_int32),
                 ("image_height", ctypes.c_int32), ("image_width", ctypes.c_int32), ("tanfovx", ctypes.c_float),
                 ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float), ("sh_degree", ctypes.c_int32),
-                ("sh_coeffs", ctypes.c_int32), ("flags", ctypes.c_int32)]
+                ("sh_coeffs", ctypes.c_int32), ("flags", ctypes.c_int32),
+                # ragged batches: sum of the sets' sizes (0 = every set has P) and the DEVICE pointer to the n_items + 1 prefix sums
+                ("total_P", ctypes.c_int32), ("item_offsets", ctypes.c_void_p)]
 
 
 class ScratchSizes(ctypes.Structure):
@@ -40,7 +42,8 @@ class ScratchSizes(ctypes.Structure):
 
 
 class HeadDesc(ctypes.Structure):
-    _fields_ = [("mode", ctypes.c_int32), ("channels", ctypes.c_int32), ("offset_scale", ctypes.c_float)]
+    _fields_ = [("mode", ctypes.c_int32), ("channels", ctypes.c_int32), ("offset_scale", ctypes.c_float),
+                ("isotropic", ctypes.c_int32)]
 
 
 class LossDesc(ctypes.Structure):

@@ -36,7 +36,9 @@ struct ProfScope {
 
 int check_desc(const u3d_raster_desc* d) {
   if (!d) return U3D_ERR_INVALID_ARGUMENT;
-  if (d->n_items < 0 || d->views_per_item < 0 || d->P < 0) return U3D_ERR_INVALID_ARGUMENT;
+  if (d->n_items < 0 || d->views_per_item < 0 || d->P < 0 || d->total_P < 0) return U3D_ERR_INVALID_ARGUMENT;
+  if ((d->total_P > 0) != (d->item_offsets != nullptr)) return U3D_ERR_INVALID_ARGUMENT;   // ragged batches bring their prefix sums
+  if (d->total_P > 0 && ((long long)d->total_P > (long long)d->n_items * d->P || d->total_P < d->P)) return U3D_ERR_INVALID_ARGUMENT;
   if (d->n_items > 65535) return U3D_ERR_UNSUPPORTED;   // items are a grid y dimension of the per-Gaussian kernels
   if (d->P > U3D_LDS_SORT_MAX && (long long)d->n_items * d->views_per_item > 65535) return U3D_ERR_UNSUPPORTED;   // (so are the views of the radix passes)
   if (d->image_height <= 0 || d->image_width <= 0) return U3D_ERR_INVALID_ARGUMENT;
@@ -47,8 +49,9 @@ int check_desc(const u3d_raster_desc* d) {
   const long long NV = (long long)d->n_items * d->views_per_item;
   const long long T = (long long)((d->image_width + U3D_TILE - 1) / U3D_TILE) * ((d->image_height + U3D_TILE - 1) / U3D_TILE);
   if (NV >= (1ll << 31) || T >= (1ll << 31) || NV * T >= (1ll << 31)) return U3D_ERR_UNSUPPORTED;
-  if ((long long)d->n_items * d->P >= (1ll << 31)) return U3D_ERR_UNSUPPORTED;
-  if (NV * d->P >= (1ll << 32)) return U3D_ERR_UNSUPPORTED;   // sorted positions / pair ids are uint32
+  const long long SP = d->total_P > 0 ? (long long)d->total_P : (long long)d->n_items * d->P;   // Gaussians in the call
+  if (SP >= (1ll << 31)) return U3D_ERR_UNSUPPORTED;
+  if (SP * d->views_per_item >= (1ll << 32)) return U3D_ERR_UNSUPPORTED;   // sorted positions / pair ids are uint32
   return U3D_OK;
 }
 
@@ -77,6 +80,7 @@ U3DSource head_source(const u3d_raster_desc& d, const u3d_head_desc& h, const fl
   src.shs = head_out + 11; src.s_shs = C;
   src.colors = nullptr; src.cov = nullptr;
   src.act = h.mode;
+  src.iso = h.isotropic != 0;
   src.center = center;
   src.offset_scale = h.offset_scale;
   src.qnorm = qnorm;
@@ -267,7 +271,7 @@ int u3d_render_loss_forward(const u3d_raster_desc* desc, const u3d_head_desc* he
   U3DSource src = head_source(d, *head, head_out, center, f.qnorm);
   if (head->mode == 1) {
     if (u3d_preprocess_sorts(d)) src.qnorm_out = f.qnorm;   // P <= 256: norms computed inside preprocess_fwd
-    else u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, nullptr, s);
+    else u3d_launch_quat_norms(d, head_out + 7, head->channels, f.qnorm, nullptr, s);
   }
   {
     ProfScope ps(0, s);
@@ -324,7 +328,7 @@ int u3d_render_loss_backward(const u3d_raster_desc* desc, const u3d_head_desc* h
     u3d_launch_preprocess_bwd(d, b, head_source(d, *head, head_out, center, f.qnorm), viewmatrix, projmatrix, campos, radii,
                               acc, sink, s);
   }
-  if (head->mode == 1) u3d_launch_quat_fixup(d.n_items, d.P, head_out + 7, C, f.qnorm, f.qdot, d_head_out + 7, s);
+  if (head->mode == 1) u3d_launch_quat_fixup(d, head_out + 7, C, f.qnorm, f.qdot, d_head_out + 7, s);
   return finish(desc, s);
 }
 
@@ -352,7 +356,7 @@ int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head,
   U3DSource src = head_source(d, *head, head_out, center, f.qnorm);
   if (head->mode == 1) {
     if (u3d_preprocess_sorts(d)) { src.qnorm_out = f.qnorm; src.qdot_zero = f.qdot; }   // P <= 256: inside preprocess_fwd
-    else u3d_launch_quat_norms(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, f.qdot, s);
+    else u3d_launch_quat_norms(d, head_out + 7, head->channels, f.qnorm, f.qdot, s);
   }
   {
     ProfScope ps(0, s);
@@ -377,7 +381,7 @@ int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head,
     ProfScope ps(4, s);
     u3d_launch_preprocess_bwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, sink, s, acc);   // reads, then re-zeroes, the touched accumulators
   }
-  if (head->mode == 1) u3d_launch_quat_fixup(d.n_items, d.P, head_out + 7, head->channels, f.qnorm, f.qdot, d_head_out + 7, s);
+  if (head->mode == 1) u3d_launch_quat_fixup(d, head_out + 7, head->channels, f.qnorm, f.qdot, d_head_out + 7, s);
   return finish(desc, s);
 }
 

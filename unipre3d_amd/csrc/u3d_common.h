@@ -51,6 +51,34 @@ struct U3DBuffers {
   uint32_t* tile_last;   // [NV*T]    last sorted position that contributed to any pixel of the tile
 };
 
+// How the sets' Gaussians are laid out (uniform: every set has P; ragged: prefix sums on the device, see u3d_raster_desc).
+//   Gaussians of set `item`:            [gbase, gbase + Pi) of the packed parameter arrays
+//   pairs of (set item, its view vk):   [vpi * gbase + vk * Pi, ... + Pi) of the per-(view, Gaussian) arrays
+// For a uniform batch this is the old arithmetic, g = view * P + i.
+struct U3DSpan {
+  const int32_t* off;   // DEVICE [n_items + 1] or null (uniform)
+  int P, vpi;
+};
+static inline U3DSpan u3d_span(const u3d_raster_desc& d) { return U3DSpan{d.total_P > 0 ? d.item_offsets : nullptr, d.P, d.views_per_item}; }
+static inline size_t u3d_total_P(const u3d_raster_desc& d) { return d.total_P > 0 ? (size_t)d.total_P : (size_t)d.n_items * (size_t)d.P; }
+#ifdef __HIPCC__
+__device__ __forceinline__ void u3d_set_span(const U3DSpan& s, int item, int& Pi, size_t& gbase) {
+  if (s.off) { const int o0 = s.off[item]; Pi = s.off[item + 1] - o0; gbase = (size_t)o0; }
+  else { Pi = s.P; gbase = (size_t)item * s.P; }
+}
+__device__ __forceinline__ size_t u3d_pair_base(const U3DSpan& s, int vk, int Pi, size_t gbase) {
+  return (size_t)s.vpi * gbase + (size_t)vk * Pi;
+}
+__device__ __forceinline__ void u3d_view_span(const U3DSpan& s, int view, int& Pv, size_t& pbase) {
+  if (s.off) {
+    const int item = view / s.vpi;
+    size_t gbase;
+    u3d_set_span(s, item, Pv, gbase);
+    pbase = u3d_pair_base(s, view - item * s.vpi, Pv, gbase);
+  } else { Pv = s.P; pbase = (size_t)view * s.P; }
+}
+#endif
+
 // Where the per-Gaussian parameters of set `item`, Gaussian `i` come from.
 //  act == 0: the operator's own tensors (means3D [P][3], shs [P][M][3], ...), strides are the natural ones.
 //  act == 1/2: the Gaussian head's raw output record (model/gaussian_predictor.py:174-181 split
@@ -68,6 +96,7 @@ struct U3DSource {
   const float* rots;    int s_rots;
   const float* cov;     // [P][6] or null
   int act;              // 0 none, 1 object-level head, 2 scene-level head
+  int iso;              // act != 0: the first scaling channel serves all three axes (cfg.model.isotropic)
   const float* center;  // [B][P][3] (act != 0)
   float offset_scale;
   const float* qnorm;   // [B][4] across-point quaternion column norms (act == 1)
@@ -125,7 +154,7 @@ static inline size_t u3d_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // single source of truth for carving; base pointers may be null when only sizes are wanted
 static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* binning, void* image, U3DBuffers* b) {
-  const size_t NV = (size_t)d.n_items * d.views_per_item, NG = NV * (size_t)d.P;
+  const size_t NV = (size_t)d.n_items * d.views_per_item, NG = (size_t)d.views_per_item * u3d_total_P(d);   // (view, Gaussian) pairs
   const size_t NP = NV * (size_t)d.image_height * d.image_width;
   U3DLayout L{};
   size_t o = 0;
@@ -189,8 +218,8 @@ void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, co
                                const U3DGradSink& sink, hipStream_t s, double* acc_reset = nullptr);
 // true when preprocess_fwd also produces the per-view depth order (P <= 256): skip u3d_launch_depth_sort then
 bool u3d_preprocess_sorts(const u3d_raster_desc& d);
-void u3d_launch_quat_norms(int n_items, int P, const float* rots, int s_rots, float* qnorm, float* qdot_zero, hipStream_t s);
-void u3d_launch_quat_fixup(int n_items, int P, const float* rots, int s_rots, const float* qnorm, const float* qdot,
+void u3d_launch_quat_norms(const u3d_raster_desc& d, const float* rots, int s_rots, float* qnorm, float* qdot_zero, hipStream_t s);
+void u3d_launch_quat_fixup(const u3d_raster_desc& d, const float* rots, int s_rots, const float* qnorm, const float* qdot,
                            float* d_rots, hipStream_t s);
 void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const int32_t* radii, hipStream_t s);
 void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,

@@ -143,6 +143,7 @@ __device__ __forceinline__ void load_gaussian(const U3DSource& src, int item, si
     g.s[0] = g.s[1] = g.s[2] = 0.f; g.q[0] = g.q[1] = g.q[2] = g.q[3] = 0.f;
   }
   if (src.act != 0) {
+    if (src.iso) g.s[1] = g.s[2] = g.s[0];   // cfg.model.isotropic: scaling[:, :1].expand(-1, 3, -1) (model/gaussian_predictor.py:308-310)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       g.th[k] = tanhf(g.p[k]);
@@ -163,7 +164,7 @@ __device__ __forceinline__ void load_gaussian(const U3DSource& src, int item, si
 
 template <int D>
 __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
-    int P, int vpi, int vpt, int H, int W, float tanx, float tany, float mod, int flags, U3DSource src,
+    U3DSpan span, int vpi, int vpt, int H, int W, float tanx, float tany, float mod, int flags, U3DSource src,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     int32_t* __restrict__ radii, float* __restrict__ depth, float2* __restrict__ xy, float4* __restrict__ conic_op,
     float4* __restrict__ rgbd, uint2* __restrict__ rect, uint32_t* __restrict__ clamped,
@@ -177,20 +178,23 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float s_rec[];   // fused mode: this block's head records, staged coalesced
   constexpr int K = (D + 1) * (D + 1);
   const int item = blockIdx.y;
+  int P;           // Gaussians of THIS set (ragged batches: blocks past the end of a short set find nothing to do)
+  size_t gbase;    // its first Gaussian in the packed parameter arrays
+  u3d_set_span(span, item, P, gbase);
   const int i0 = blockIdx.x * U3D_BLOCK;
   const int i = i0 + threadIdx.x;
   const int v0 = blockIdx.z * vpt, v1 = min(vpi, v0 + vpt);
   U3DSource lsrc = src;
-  size_t gi = (size_t)item * P + (i < P ? i : 0);
+  size_t gi = gbase + (i < P ? i : 0);
   if (src.act != 0) {
     // rows i0 .. i0+255 of head_out are contiguous: coalesced copy into LDS, then row-strided reads (C odd: no conflicts)
     const int C = src.s_means;
     const int nrow = min(U3D_BLOCK, P - i0);
-    const float* rows = src.means + ((size_t)item * P + i0) * C;
+    const float* rows = src.means + (gbase + i0) * C;
     for (int e = threadIdx.x; e < nrow * C; e += U3D_BLOCK) s_rec[e] = rows[e];
     __syncthreads();
     lsrc.means = s_rec; lsrc.opac = s_rec + 3; lsrc.scales = s_rec + 4; lsrc.rots = s_rec + 7; lsrc.shs = s_rec + 11;
-    lsrc.center = src.center + ((size_t)item * P + i0) * 3;
+    lsrc.center = src.center + (gbase + i0) * 3;
     if (src.act == 1 && src.qnorm_out) {
       // the block holds the whole set: across-point quaternion column norms from the staged records (same summation
       // order as quat_norms_kernel); the first view slice publishes them for the backward and clears qdot
@@ -243,11 +247,12 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
   }
   for (int vk = v0; vk < v1; ++vk) {
   const int view = item * vpi + vk;
+  const size_t pbase = u3d_pair_base(span, vk, P, gbase);   // first (view, Gaussian) pair of this view
   uint32_t touched = 0;
   unsigned long long sort_key = ~0ull;
   uint2 sort_rect = make_uint2(0u, 0u);
   if (i < P) {
-    const size_t g = (size_t)view * P + i;
+    const size_t g = pbase + i;
     Cam cam;
     load_cam(cam, viewmatrix, projmatrix, campos, view);
     const float* p = gin.p;
@@ -348,8 +353,8 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     if (vis && (tid == U3D_BLOCK - 1 || s_keys[tid + 1] == ~0ull)) n_vis[view] = (uint32_t)(tid + 1);
     if (tid < P) {
       const uint32_t id = vis ? (uint32_t)kk : 0u;
-      sorted_id[(size_t)view * P + tid] = id;
-      sorted_rect[(size_t)view * P + tid] = vis ? s_rects[id] : make_uint2(0u, 0u);
+      sorted_id[pbase + tid] = id;
+      sorted_rect[pbase + tid] = vis ? s_rects[id] : make_uint2(0u, 0u);
     }
   }
   }
@@ -358,17 +363,21 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
 // ---------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
-    int P, int vpi, int M, int H, int W, float tanx, float tany, float mod, int flags, size_t NG, U3DSource src,
+    U3DSpan span, int vpi, int M, int H, int W, float tanx, float tany, float mod, int flags, size_t NG, U3DSource src,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const double* acc, double* acc_reset,
     U3DGradSink sink) {
   // 4 consecutive lanes (a DPP quad) share one Gaussian and split its views: lane&3 = view slot
   __shared__ float s_qdot[4][4];
   const int item = blockIdx.y;
+  int P;
+  size_t gbase;
+  u3d_set_span(span, item, P, gbase);
+  const size_t pbase0 = u3d_pair_base(span, 0, P, gbase);   // pairs of (this set, view slot vk): pbase0 + vk * P + i
   const int vslot = threadIdx.x & 3;
   const int i = blockIdx.x * (U3D_BLOCK / 4) + (threadIdx.x >> 2);
   const bool alive = i < P;
-  const size_t gi = (size_t)item * P + (alive ? i : 0);
+  const size_t gi = gbase + (alive ? i : 0);
   constexpr int K = (D + 1) * (D + 1);
   const bool writer = alive && vslot == 0;
   float qd[4] = {0.f, 0.f, 0.f, 0.f};
@@ -379,21 +388,21 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
   bool lane_live = (flags & U3D_FLAG_INTERNAL_TRIAGE) == 0;
   if (!lane_live) {
     for (int vk = vslot; vk < (alive ? vpi : 0); vk += 4) {
-      const size_t g = (size_t)(item * vpi + vk) * P + i;
+      const size_t g = pbase0 + (size_t)vk * P + i;
       lane_live = lane_live || (radii[g] > 0 && (clamped[g] & U3D_TOUCHED_BIT) != 0u);
     }
   }
   if (__ballot(lane_live) == 0ull) {
     if (sink.means2D) {
       for (int vk = vslot; vk < (alive ? vpi : 0); vk += 4) {
-        const size_t g = (size_t)(item * vpi + vk) * P + i;
+        const size_t g = pbase0 + (size_t)vk * P + i;
         sink.means2D[g * 3] = 0.f; sink.means2D[g * 3 + 1] = 0.f; sink.means2D[g * 3 + 2] = 0.f;
       }
     }
     if (src.act != 0) {
       // fused mode: the gradient rows of the wave's 16 Gaussians are 16 * C consecutive floats of d(head output)
       const int C = src.s_means, iw = blockIdx.x * (U3D_BLOCK / 4) + (threadIdx.x >> 6) * 16, n = min(16, P - iw) * C;
-      float* o = sink.means + ((size_t)item * P + iw) * C;
+      float* o = sink.means + (gbase + iw) * C;
       for (int e = threadIdx.x & 63; e < n; e += 64) o[e] = 0.f;
     } else if (writer) {
 #pragma unroll
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
 
   for (int vk = vslot; vk < (alive ? vpi : 0); vk += 4) {
     const int view = item * vpi + vk;
-    const size_t g = (size_t)view * P + i;
+    const size_t g = pbase0 + (size_t)vk * P + i;
     const uint32_t cbits = clamped[g];
     const bool live = radii[g] > 0 && (cbits & U3D_TOUCHED_BIT) != 0u;   // visible AND handed a gradient by the reduction
     float a[U3D_NACC];
@@ -651,6 +660,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
         dscale[k] *= (gin.raw_s[k] >= -1.f && gin.raw_s[k] <= 20.f) ? s[k] : 0.f;
       }
       dop *= op_in * (1.f - op_in);
+      if (src.iso) { dscale[0] += dscale[1] + dscale[2]; dscale[1] = dscale[2] = 0.f; }   // one raw channel fed all three axes
       if (src.act == 2) {
         // per-quaternion normalise: d x_j = g_j / n - x_j (g . x) / n^3   (n > eps), g_j / eps otherwise
         const float n2 = gin.raw_q[0] * gin.raw_q[0] + gin.raw_q[1] * gin.raw_q[1] + gin.raw_q[2] * gin.raw_q[2] + gin.raw_q[3] * gin.raw_q[3];
@@ -705,13 +715,16 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
 
 // across-point quaternion norms: qnorm[item][c] = || raw_rot[item, :, c] ||_2   (F.normalize(x(B,4,N), dim=-1))
 constexpr int QN_THREADS = 1024;   // one workgroup per set: 16 waves keep more of the strided loads in flight (7.5 -> ~4 us at P = 2048)
-__global__ __launch_bounds__(QN_THREADS) void quat_norms_kernel(int P, const float* __restrict__ rots, int s_rots,
+__global__ __launch_bounds__(QN_THREADS) void quat_norms_kernel(U3DSpan span, const float* __restrict__ rots, int s_rots,
                                                                 float* __restrict__ qnorm, float* __restrict__ qdot_zero) {
   __shared__ float sm[QN_THREADS / 64][4];
   const int item = blockIdx.x;
+  int P;
+  size_t gbase;
+  u3d_set_span(span, item, P, gbase);
   float a[4] = {0.f, 0.f, 0.f, 0.f};
   for (int i = threadIdx.x; i < P; i += QN_THREADS) {
-    const float* r = rots + ((size_t)item * P + i) * s_rots;
+    const float* r = rots + (gbase + i) * s_rots;
 #pragma unroll
     for (int k = 0; k < 4; ++k) a[k] += r[k] * r[k];
   }
@@ -732,13 +745,16 @@ __global__ __launch_bounds__(QN_THREADS) void quat_norms_kernel(int P, const flo
 }
 
 // second term of the across-point normalise backward: d x_i -= x_i * (sum_j x_j g_j) / n^3  when n > eps
-__global__ __launch_bounds__(U3D_BLOCK) void quat_fixup_kernel(int P, const float* __restrict__ rots, int s_rots,
+__global__ __launch_bounds__(U3D_BLOCK) void quat_fixup_kernel(U3DSpan span, const float* __restrict__ rots, int s_rots,
                                                                const float* __restrict__ qnorm, const float* __restrict__ qdot,
                                                                float* __restrict__ d_rots) {
   const int item = blockIdx.y;
+  int P;
+  size_t gbase;
+  u3d_set_span(span, item, P, gbase);
   const int i = blockIdx.x * U3D_BLOCK + threadIdx.x;
   if (i >= P) return;
-  const size_t o = ((size_t)item * P + i) * s_rots;
+  const size_t o = (gbase + i) * s_rots;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float n = qnorm[item * 4 + k];
@@ -761,15 +777,15 @@ bool u3d_preprocess_sorts(const u3d_raster_desc& d) { return d.P <= U3D_BLOCK; }
 void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, int32_t* radii, double* acc_zero, hipStream_t s) {
   const bool fuse_sort = u3d_preprocess_sorts(d);
-  const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
+  const size_t NG = (size_t)d.views_per_item * u3d_total_P(d);
   // enough Gaussians to fill the chip by themselves -> one thread walks all views of its set; otherwise split the views
-  const int vpt = ((size_t)d.P * d.n_items >= 65536) ? d.views_per_item : 1;
+  const int vpt = (u3d_total_P(d) >= 65536) ? d.views_per_item : 1;
   const int chunks = (d.views_per_item + vpt - 1) / vpt;
   dim3 grid((d.P + U3D_BLOCK - 1) / U3D_BLOCK, d.n_items, chunks), block(U3D_BLOCK);
   const size_t lds = src.act != 0 ? (size_t)U3D_BLOCK * src.s_means * sizeof(float) : 0;
   const int D = src.shs ? d.sh_degree : 0;
 #define LAUNCH(DEG)                                                                                                   \
-  hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, lds, s, d.P, d.views_per_item, vpt, d.image_height,     \
+  hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, lds, s, u3d_span(d), d.views_per_item, vpt, d.image_height, \
                      d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, src, viewmatrix, projmatrix, campos, \
                      radii, b.depth, b.xy, b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered, acc_zero, NG,               \
                      fuse_sort ? b.sorted_id : nullptr, b.sorted_rect, b.n_vis)
@@ -785,12 +801,12 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, const int32_t* radii, const double* acc,
                                const U3DGradSink& sink, hipStream_t s, double* acc_reset) {
-  const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
+  const size_t NG = (size_t)d.views_per_item * u3d_total_P(d);
   dim3 grid((d.P + U3D_BLOCK / 4 - 1) / (U3D_BLOCK / 4), d.n_items), block(U3D_BLOCK);
   const int D = src.shs ? d.sh_degree : 0;
   const int flags = d.flags | (d.P > U3D_LDS_SORT_MAX ? U3D_FLAG_INTERNAL_TRIAGE : 0);   // scene level: most waves only write zeros
 #define LAUNCH(DEG)                                                                                                    \
-  hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, d.P, d.views_per_item, d.sh_coeffs, d.image_height, \
+  hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, u3d_span(d), d.views_per_item, d.sh_coeffs, d.image_height, \
                      d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, flags, NG, src, viewmatrix, projmatrix,    \
                      campos, radii, b.clamped, acc, acc_reset, sink)
   switch (D) {
@@ -802,13 +818,13 @@ void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 #undef LAUNCH
 }
 
-void u3d_launch_quat_norms(int n_items, int P, const float* rots, int s_rots, float* qnorm, float* qdot_zero, hipStream_t s) {
-  hipLaunchKernelGGL(quat_norms_kernel, dim3(n_items), dim3(QN_THREADS), 0, s, P, rots, s_rots, qnorm, qdot_zero);
+void u3d_launch_quat_norms(const u3d_raster_desc& d, const float* rots, int s_rots, float* qnorm, float* qdot_zero, hipStream_t s) {
+  hipLaunchKernelGGL(quat_norms_kernel, dim3(d.n_items), dim3(QN_THREADS), 0, s, u3d_span(d), rots, s_rots, qnorm, qdot_zero);
 }
 
-void u3d_launch_quat_fixup(int n_items, int P, const float* rots, int s_rots, const float* qnorm, const float* qdot,
+void u3d_launch_quat_fixup(const u3d_raster_desc& d, const float* rots, int s_rots, const float* qnorm, const float* qdot,
                            float* d_rots, hipStream_t s) {
-  hipLaunchKernelGGL(quat_fixup_kernel, dim3((P + U3D_BLOCK - 1) / U3D_BLOCK, n_items), dim3(U3D_BLOCK), 0, s, P, rots,
+  hipLaunchKernelGGL(quat_fixup_kernel, dim3((d.P + U3D_BLOCK - 1) / U3D_BLOCK, d.n_items), dim3(U3D_BLOCK), 0, s, u3d_span(d), rots,
                      s_rots, qnorm, qdot, d_rots);
 }
 

@@ -512,11 +512,14 @@ static_assert(TILE_WAVES == 1, "one wave = one workgroup = one tile");
     pxf[k] = (float)(px0 + k);                                                                          \
     inside[k] = px0 + k < W && py < H;                                                                  \
   }                                                                                                     \
-  const TileGeom G{sorted_id, sorted_rect, xy, conic_op, rgbd, (size_t)view * P, tx, ty, touched}
+  int Pv_;        /* Gaussians of this view's set; first (view, Gaussian) pair (uniform batch: view * P, no division) */ \
+  size_t vb_;                                                                                            \
+  u3d_view_span(span, view, Pv_, vb_);                                                                   \
+  const TileGeom G{sorted_id, sorted_rect, xy, conic_op, rgbd, vb_, tx, ty, touched}
 
 // ---- forward (operator path): colour, inverse depth, and the state the backward kernel restarts from --------
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
-    int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, const uint32_t* __restrict__ sorted_id,
+    U3DSpan span, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, const uint32_t* __restrict__ sorted_id,
     const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis, const float2* __restrict__ xy,
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
 // ---- backward (operator path, and second pass of the two-pass fused loss) ------------------------------------
 template <bool HAS_INVD, int PB>
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
-    int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, size_t NG,
+    U3DSpan span, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, size_t NG,
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const float2* __restrict__ xy,
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_dinvdepth, const float* __restrict__ final_T,
@@ -636,7 +639,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
 // disappears.  dL/dloss is taken as 1 (the result is linear in it; the host scales the stored gradient).
 template <int PB>
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void render_fb_wave_kernel(
-    int P, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, size_t NG,
+    U3DSpan span, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, size_t NG,
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis,
     const float2* __restrict__ xy, const float4* __restrict__ conic_op, const float4* __restrict__ rgbd,
     const float* __restrict__ bg, float* __restrict__ out_color, double* __restrict__ acc, float* __restrict__ part,
@@ -699,7 +702,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
 constexpr int REDUCE_THREADS = U3D_WAVE * 10;
 #define RU 32   // tiles in flight per thread
 template <int PB>
-__global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T, int NK, int nsplit, size_t NG, float half_w, float half_h,
+__global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(U3DSpan span, int T, int NK, int nsplit, size_t NG, float half_w, float half_h,
                                                                    const uint32_t* __restrict__ sorted_id,
                                                                    const float4* __restrict__ conic_op,
                                                                    const float* __restrict__ part,
@@ -791,7 +794,10 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T
 #pragma unroll
       for (int j = 0; j < U3D_NACC; ++j) any = any || m[j] != 0.0;
       if (any) {
-        const size_t g = (size_t)view * P + sorted_id[(size_t)view * P + spos];
+        int Pv;
+        size_t vb;
+        u3d_view_span(span, view, Pv, vb);
+        const size_t g = vb + sorted_id[vb + spos];
         const float4 co = conic_op[g];
         const double outv = moment_to_acc<double>(k, m, co.x, co.y, co.z, co.w, half_w, half_h);
         if (outv != 0.0) unsafeAtomicAdd(&acc[(size_t)k * NG + g], outv);
@@ -803,7 +809,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(int P, int T
 
 // Single-block form (object level: every tile's rows fit the first 64 positions): the same reduction with the block loop
 // and the per-tile stride folded away (the generic instantiation measured 2 us slower at C2).
-__global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce1_kernel(int P, int T, int NK, int nsplit, size_t NG, float half_w, float half_h,
+__global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce1_kernel(U3DSpan span, int T, int NK, int nsplit, size_t NG, float half_w, float half_h,
                                                                    const uint32_t* __restrict__ sorted_id,
                                                                    const float4* __restrict__ conic_op,
                                                                    const float* __restrict__ part,
@@ -887,7 +893,10 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce1_kernel(int P, int 
 #pragma unroll
   for (int j = 0; j < U3D_NACC; ++j) any = any || m[j] != 0.0;
   if (!any) return;
-  const size_t g = (size_t)view * P + sorted_id[(size_t)view * P + sp];
+  int Pv;
+  size_t vb;
+  u3d_view_span(span, view, Pv, vb);
+  const size_t g = vb + sorted_id[vb + sp];
   const float4 co = conic_op[g];
   const double outv = moment_to_acc<double>(k, m, co.x, co.y, co.z, co.w, half_w, half_h);
   if (outv != 0.0) unsafeAtomicAdd(&acc[(size_t)k * NG + g], outv);
@@ -938,7 +947,7 @@ void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   const uint32_t ntiles = (uint32_t)(d.n_items * d.views_per_item * T);
   if (ntiles == 0) return;
   const TileGrid tg = tile_grid(d, tiles_x, T);
-  hipLaunchKernelGGL(render_fwd_wave_kernel, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
+  hipLaunchKernelGGL(render_fwd_wave_kernel, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height, d.image_width,
                      tiles_x, T, ntiles, tg.magic, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
                      out_invdepth, b.final_T, b.n_contrib, b.tile_last, loss);
 }
@@ -948,21 +957,21 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
   const int tiles_x = (d.image_width + U3D_TILE - 1) / U3D_TILE, tiles_y = (d.image_height + U3D_TILE - 1) / U3D_TILE;
   const int T = tiles_x * tiles_y;
   const uint32_t ntiles = (uint32_t)(d.n_items * d.views_per_item * T);
-  const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
+  const size_t NG = (size_t)d.views_per_item * u3d_total_P(d);
   if (ntiles == 0 || NG == 0) return;
   const TileGrid tg = tile_grid(d, tiles_x, T);
   if (u3d_part_blocks(d) == 1)
-    hipLaunchKernelGGL(render_fb_wave_kernel<1>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, d.image_width,
+    hipLaunchKernelGGL(render_fb_wave_kernel<1>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height, d.image_width,
                        tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
                        acc, part, b.clamped, loss);
   else
-    hipLaunchKernelGGL(render_fb_wave_kernel<U3D_PART_BLOCKS>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height,
+    hipLaunchKernelGGL(render_fb_wave_kernel<U3D_PART_BLOCKS>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height,
                        d.image_width, tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg,
                        out_color, acc, part, b.clamped, loss);
   const int nsplit = bwd_reduce_split(T, d.n_items * d.views_per_item);
   auto* reduce_k = u3d_part_blocks(d) == 1 ? bwd_reduce1_kernel : bwd_reduce_kernel<U3D_PART_BLOCKS>;
   hipLaunchKernelGGL(reduce_k, dim3(d.n_items * d.views_per_item, nsplit + 1), dim3(REDUCE_THREADS), 0, s,
-                     d.P, T, U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id, b.conic_op, part,
+                     u3d_span(d), T, U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id, b.conic_op, part,
                      reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, (int)ntiles, loss.partial,
                      loss.inv_count, loss_out);
 }
@@ -973,12 +982,12 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   const int tiles_x = (d.image_width + U3D_TILE - 1) / U3D_TILE, tiles_y = (d.image_height + U3D_TILE - 1) / U3D_TILE;
   const int T = tiles_x * tiles_y;
   const uint32_t ntiles = (uint32_t)(d.n_items * d.views_per_item * T);
-  const size_t NG = (size_t)d.n_items * d.views_per_item * d.P;
+  const size_t NG = (size_t)d.views_per_item * u3d_total_P(d);
   if (ntiles == 0 || NG == 0) return;
   const TileGrid tg = tile_grid(d, tiles_x, T);
   const bool invd = dL_dinvdepth && loss.kind == 0;
 #define LAUNCH(INVD, PBV)                                                                                                   \
-  hipLaunchKernelGGL((render_bwd_wave_kernel<INVD, PBV>), tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, d.P, d.image_height, \
+  hipLaunchKernelGGL((render_bwd_wave_kernel<INVD, PBV>), tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height, \
                      d.image_width, tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg,    \
                      dL_dcolor, dL_dinvdepth, b.final_T, b.n_contrib, b.tile_last, acc, part, out_color, b.clamped, loss)
   if (u3d_part_blocks(d) == 1) { if (invd) LAUNCH(true, 1); else LAUNCH(false, 1); }
@@ -987,7 +996,7 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   const int nsplit = bwd_reduce_split(T, d.n_items * d.views_per_item);
   auto* reduce_k = u3d_part_blocks(d) == 1 ? bwd_reduce1_kernel : bwd_reduce_kernel<U3D_PART_BLOCKS>;
   hipLaunchKernelGGL(reduce_k, dim3(d.n_items * d.views_per_item, nsplit), dim3(REDUCE_THREADS), 0, s,
-                     d.P, T, invd ? U3D_NACC : U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id,
+                     u3d_span(d), T, invd ? U3D_NACC : U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id,
                      b.conic_op, part, reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, 0, nullptr, 0.f,
                      nullptr);
 }

@@ -22,7 +22,7 @@ namespace {
 // become destinations through one prefix over the waves.  1024 threads (a lone 4-wave workgroup per CU cannot hide its own
 // LDS and barrier latency: 34 us); measured at C3 (P = 2048, 64 views): 21 us against 32 us for a 66-stage bitonic network.
 template <int NT>
-__global__ __launch_bounds__(NT) void depth_sort_block_radix_kernel(int P, int N, const float* __restrict__ depth,
+__global__ __launch_bounds__(NT) void depth_sort_block_radix_kernel(U3DSpan span, int N, const float* __restrict__ depth,
                                                                     const int32_t* __restrict__ radii,
                                                                     const uint2* __restrict__ rect,
                                                                     uint32_t* __restrict__ sorted_id,
@@ -37,7 +37,9 @@ __global__ __launch_bounds__(NT) void depth_sort_block_radix_kernel(int P, int N
   uint32_t* vals[2] = {lds + 2 * N, lds + 3 * N};
   const int view = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
   const uint32_t lane = u3d_lane_id();
-  const size_t base = (size_t)view * P;
+  int P;          // Gaussians of this view's set (<= N)
+  size_t base;    // its first (view, Gaussian) pair
+  u3d_view_span(span, view, P, base);
   const int rounds = N / NT;
   for (int i = tid; i < N; i += NT) {
     keys[0][i] = (i < P && radii[base + i] > 0) ? __float_as_uint(depth[base + i]) : 0xFFFFFFFFu;
@@ -138,11 +140,13 @@ __device__ __forceinline__ uint32_t msd_key(int P, int idx, size_t base, const f
 __device__ __forceinline__ uint32_t msd_bucket(uint32_t k) { return min(k >> MSD_SHIFT, (uint32_t)(MSD_BINS - 1)); }
 
 template <int NT, int ITEMS>
-__global__ __launch_bounds__(NT) void msd_hist_kernel(int P, int nblk, const float* __restrict__ depth, const int32_t* __restrict__ radii,
+__global__ __launch_bounds__(NT) void msd_hist_kernel(U3DSpan span, int nblk, const float* __restrict__ depth, const int32_t* __restrict__ radii,
                                                       uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[MSD_BINS];
   const int view = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
-  const size_t base = (size_t)view * P;
+  int P;
+  size_t base;
+  u3d_view_span(span, view, P, base);
   if (tid < MSD_BINS) h[tid] = 0;
   __syncthreads();
 #pragma unroll
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(NT) void msd_hist_kernel(int P, int nblk, const flo
 }
 
 template <int NT, int ITEMS>
-__global__ __launch_bounds__(NT) void msd_scatter_kernel(int P, int nblk, const float* __restrict__ depth, const int32_t* __restrict__ radii,
+__global__ __launch_bounds__(NT) void msd_scatter_kernel(U3DSpan span, int nblk, const float* __restrict__ depth, const int32_t* __restrict__ radii,
                                                          uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                          const uint32_t* __restrict__ hist, uint32_t* __restrict__ n_vis,
                                                          uint32_t* __restrict__ bucket_off) {
@@ -171,7 +175,9 @@ __global__ __launch_bounds__(NT) void msd_scatter_kernel(int P, int nblk, const 
   const int view = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6;
   const uint32_t lane = u3d_lane_id();
-  const size_t base = (size_t)view * P;
+  int P;
+  size_t base;
+  u3d_view_span(span, view, P, base);
   for (int e = tid; e < 2 * NW * MSD_BINS; e += NT) (&wave_cnt[0][0][0])[e] = 0;
   {
     // global offset of (bucket tid, this block) in bucket-major / block-minor order, from the per-block counts hist[view][b][bucket]
@@ -309,7 +315,7 @@ __device__ __forceinline__ void wg_radix_pass(const uint32_t* kin, const uint32_
 }
 
 template <int BUCKET_NT>   // 256 threads per bucket up to 64 k Gaussians per view, 512 beyond (denser buckets: C5 sort 97 -> 85 us, C4 49 -> 52)
-__global__ __launch_bounds__(BUCKET_NT) void bucket_sort_kernel(int P, int lds_cap, uint32_t* __restrict__ keys0, uint32_t* __restrict__ vals0,
+__global__ __launch_bounds__(BUCKET_NT) void bucket_sort_kernel(U3DSpan span, int lds_cap, uint32_t* __restrict__ keys0, uint32_t* __restrict__ vals0,
                                                                 uint32_t* __restrict__ keys1, uint32_t* __restrict__ vals1,
                                                                 const uint32_t* __restrict__ bucket_off, const uint2* __restrict__ rect,
                                                                 uint32_t* __restrict__ sorted_id, uint2* __restrict__ sorted_rect) {
@@ -319,7 +325,9 @@ __global__ __launch_bounds__(BUCKET_NT) void bucket_sort_kernel(int P, int lds_c
   __shared__ uint32_t digit_base[1 << BITS];
   __shared__ uint32_t wave_cnt[2][NW][1 << BITS];
   const int view = blockIdx.y, bucket = blockIdx.x, tid = threadIdx.x;
-  const size_t base = (size_t)view * P;
+  int P;
+  size_t base;
+  u3d_view_span(span, view, P, base);
   const uint32_t start = bucket_off[(size_t)view * (MSD_BINS + 1) + bucket], end = bucket_off[(size_t)view * (MSD_BINS + 1) + bucket + 1];
   const int n = (int)(end - start);
   if (n == 0) {
@@ -375,10 +383,10 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
         attr_set = true;
       }
       if (NT == 1024)
-        hipLaunchKernelGGL(depth_sort_block_radix_kernel<1024>, dim3(NV), dim3(1024), (size_t)4 * N * sizeof(uint32_t), s, d.P, N, b.depth,
+        hipLaunchKernelGGL(depth_sort_block_radix_kernel<1024>, dim3(NV), dim3(1024), (size_t)4 * N * sizeof(uint32_t), s, u3d_span(d), N, b.depth,
                            radii, b.rect, b.sorted_id, b.sorted_rect, b.n_vis);
       else
-        hipLaunchKernelGGL(depth_sort_block_radix_kernel<256>, dim3(NV), dim3(256), (size_t)4 * N * sizeof(uint32_t), s, d.P, N, b.depth,
+        hipLaunchKernelGGL(depth_sort_block_radix_kernel<256>, dim3(NV), dim3(256), (size_t)4 * N * sizeof(uint32_t), s, u3d_span(d), N, b.depth,
                            radii, b.rect, b.sorted_id, b.sorted_rect, b.n_vis);
     }
     return;
@@ -402,17 +410,17 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
                                 4 * 4096 * (int)sizeof(uint32_t));                                                          \
       attr = true;                                                                                                           \
     }                                                                                                                        \
-    hipLaunchKernelGGL((msd_hist_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), 0, s, d.P, nblk, b.depth, radii, b.sort_hist);   \
-    hipLaunchKernelGGL((msd_scatter_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), lds, s, d.P, nblk, b.depth, radii,            \
+    hipLaunchKernelGGL((msd_hist_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), 0, s, u3d_span(d), nblk, b.depth, radii, b.sort_hist);   \
+    hipLaunchKernelGGL((msd_scatter_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), lds, s, u3d_span(d), nblk, b.depth, radii,            \
                        b.sort_keys[0], b.sort_vals[0], b.sort_hist, b.n_vis, b.sort_over);                                   \
   } while (0)
   if (d.P <= 65536) LAUNCH(U3D_RADIX_NT_SMALL, U3D_RADIX_IT_SMALL); else LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE);
 #undef LAUNCH
   const int cap = lds_cap < 1 ? 1 : (lds_cap > 4096 ? 4096 : lds_cap);
   if (d.P <= 65536)
-    hipLaunchKernelGGL(bucket_sort_kernel<256>, dim3(MSD_BINS, NV), dim3(256), (size_t)4 * cap * sizeof(uint32_t), s, d.P, cap, b.sort_keys[0],
+    hipLaunchKernelGGL(bucket_sort_kernel<256>, dim3(MSD_BINS, NV), dim3(256), (size_t)4 * cap * sizeof(uint32_t), s, u3d_span(d), cap, b.sort_keys[0],
                        b.sort_vals[0], b.sort_keys[1], b.sort_vals[1], b.sort_over, b.rect, b.sorted_id, b.sorted_rect);
   else
-    hipLaunchKernelGGL(bucket_sort_kernel<512>, dim3(MSD_BINS, NV), dim3(512), (size_t)4 * cap * sizeof(uint32_t), s, d.P, cap, b.sort_keys[0],
+    hipLaunchKernelGGL(bucket_sort_kernel<512>, dim3(MSD_BINS, NV), dim3(512), (size_t)4 * cap * sizeof(uint32_t), s, u3d_span(d), cap, b.sort_keys[0],
                        b.sort_vals[0], b.sort_keys[1], b.sort_vals[1], b.sort_over, b.rect, b.sorted_id, b.sorted_rect);
 }

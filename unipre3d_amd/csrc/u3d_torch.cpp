@@ -102,7 +102,9 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
   static variable_list forward(AutogradContext* ctx, Tensor means3D, OptTensor means2D_, OptTensor shs_, OptTensor colors_, Tensor opac,
                                OptTensor scales_, OptTensor rots_, OptTensor cov_, Tensor view, Tensor proj, Tensor campos, Tensor bg,
                                int64_t n_items, int64_t vpi, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier,
-                               int64_t sh_degree, int64_t flags, bool single) {
+                               int64_t sh_degree, int64_t flags, bool single, OptTensor item_offsets_, int64_t max_P) {
+    // ragged batch (item_offsets given): per-Gaussian tensors are PACKED (total_P, ...), max_P is the largest set; the per-(view,
+    // Gaussian) outputs radii / dL_dmeans2D are packed (views_per_item * total_P, ...) in the layout of u3d_raster_desc
     // single: ONE view of ONE set with the reference operator's own tensor shapes (means3D (P,3) ... -> color (3,H,W)); no
     // leading set / view dimension, so no unsqueeze / squeeze nodes surround the call in the autograd graph
     const c10::Device dev = means3D.device();
@@ -111,23 +113,37 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     auto val = [](const OptTensor& t) { return t.has_value() ? *t : Tensor(); };
     const Tensor shs = val(shs_), colors = val(colors_), scales = val(scales_), rots = val(rots_), cov = val(cov_);
     // (means2D carries no data forward: it is the gradient sink `viewspace_points` of gaussian_renderer/__init__.py:29)
-    const int64_t P = means3D.numel() > 0 ? means3D.size(-2) : 0;
+    const bool ragged = item_offsets_.has_value() && item_offsets_->defined();
+    const int64_t total_P = ragged ? means3D.size(0) : 0;
+    const int64_t P = ragged ? max_P : (means3D.numel() > 0 ? means3D.size(-2) : 0);
     const int64_t M = shs.defined() ? shs.size(-2) : 0;
+    Tensor offsets;
+    if (ragged) {
+      offsets = *item_offsets_;
+      TORCH_CHECK(offsets.device() == dev && offsets.scalar_type() == at::kInt && offsets.is_contiguous() && offsets.numel() == n_items + 1,
+                  "item_offsets must be a contiguous int32 tensor of n_items + 1 prefix sums on the Gaussians' device");
+      TORCH_CHECK(!single && total_P > 0 && max_P > 0 && max_P <= total_P, "ragged batch: bad total / largest set size");
+    }
     u3d_raster_desc d{};
     d.n_items = (int32_t)n_items; d.views_per_item = (int32_t)vpi; d.P = (int32_t)P;
     d.image_height = (int32_t)H; d.image_width = (int32_t)W;
     d.tanfovx = (float)tanfovx; d.tanfovy = (float)tanfovy; d.scale_modifier = (float)scale_modifier;
     d.sh_degree = (int32_t)sh_degree; d.sh_coeffs = (int32_t)M; d.flags = (int32_t)flags;
+    d.total_P = (int32_t)total_P;
+    d.item_offsets = ragged ? (const int32_t*)8 : nullptr;     // (the plan depends on whether it is set, not on where it points)
     const Plan& plan = plan_for(d);
+    u3d_raster_desc dd = plan.d;                               // this call's descriptor: the plan's shape + the device pointer
+    dd.item_offsets = ragged ? offsets.data_ptr<int32_t>() : nullptr;
     const int64_t NV = n_items * vpi;
     const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
     Tensor color = single ? at::empty({3, H, W}, fopt) : at::empty({NV, 3, H, W}, fopt);
     Tensor invdepth = single ? at::empty({1, H, W}, fopt) : at::empty({NV, 1, H, W}, fopt);
     // (every (view, Gaussian) radius is written by the projection kernel)
-    Tensor radii = single ? at::empty({P}, fopt.dtype(at::kInt)) : at::empty({NV, P}, fopt.dtype(at::kInt));
+    Tensor radii = single ? at::empty({P}, fopt.dtype(at::kInt))
+                          : (ragged ? at::empty({vpi * total_P}, fopt.dtype(at::kInt)) : at::empty({NV, P}, fopt.dtype(at::kInt)));
     Tensor arena = at::empty({(int64_t)plan.fwd_scratch}, fopt.dtype(at::kByte));   // geom | binning | image
     char* base = (char*)arena.data_ptr();
-    const int rc = u3d_rasterize_forward(&plan.d, fptr(bg), fptr(means3D), fptr(shs), fptr(colors), fptr(opac), fptr(scales), fptr(rots),
+    const int rc = u3d_rasterize_forward(&dd, fptr(bg), fptr(means3D), fptr(shs), fptr(colors), fptr(opac), fptr(scales), fptr(rots),
                                          fptr(cov), fptr(view), fptr(proj), fptr(campos), color.data_ptr<float>(), invdepth.data_ptr<float>(),
                                          P > 0 ? radii.data_ptr<int32_t>() : nullptr, base, base + plan.o_binning, base + plan.o_image,
                                          current_stream(dev));
@@ -136,7 +152,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     ctx->saved_data["has_colors"] = colors.defined();
     ctx->saved_data["single"] = single;
     ctx->saved_data["has_means2D"] = means2D_.has_value() && means2D_->defined();
-    ctx->save_for_backward({means3D, shs, colors, opac, scales, rots, cov, view, proj, campos, bg, radii, arena});
+    ctx->save_for_backward({means3D, shs, colors, opac, scales, rots, cov, view, proj, campos, bg, radii, arena, offsets});
     ctx->mark_non_differentiable({radii});
     ctx->set_materialize_grads(false);    // unused outputs (invdepth) arrive undefined, not as a zero tensor
     return {color, radii, invdepth};
@@ -149,7 +165,8 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     const bool has_m2d = ctx->saved_data["has_means2D"].toBool();
     auto sv = ctx->get_saved_variables();
     const Tensor &means3D = sv[0], &shs = sv[1], &colors = sv[2], &opac = sv[3], &scales = sv[4], &rots = sv[5], &cov = sv[6], &view = sv[7],
-                 &proj = sv[8], &campos = sv[9], &bg = sv[10], &radii = sv[11], &arena = sv[12];
+                 &proj = sv[8], &campos = sv[9], &bg = sv[10], &radii = sv[11], &arena = sv[12], &offsets = sv[13];
+    const bool ragged = offsets.defined();
     const u3d_raster_desc& d = plan.d;
     const c10::Device dev = means3D.device();
     const int64_t NV = (int64_t)d.n_items * d.views_per_item, P = d.P, M = d.sh_coeffs, n = d.n_items;
@@ -160,21 +177,30 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     if (ginv.defined()) ginv = f32c(ginv, dev);
     const bool live = P > 0 && NV > 0;
     // the backward kernels write every element of every gradient they are handed (zeros for culled / untouched Gaussians)
-    auto out = [&](std::initializer_list<int64_t> shape) {
-      std::vector<int64_t> sh(shape.begin() + (single ? 1 : 0), shape.end());     // single: drop the leading set / view dimension
+    // gradient of a per-Gaussian input (per_view false) or of the per-(view, Gaussian) sink means2D (true), trailing dims `tail`:
+    //   uniform (sets | views, P, tail...)   single (P, tail...)   ragged, packed (total_P | views_per_item * total_P, tail...)
+    auto out = [&](bool per_view, std::initializer_list<int64_t> tail) {
+      std::vector<int64_t> sh;
+      if (ragged) sh.push_back(per_view ? (int64_t)d.views_per_item * d.total_P : (int64_t)d.total_P);
+      else {
+        if (!single) sh.push_back(per_view ? NV : n);
+        sh.push_back(P);
+      }
+      sh.insert(sh.end(), tail.begin(), tail.end());
       return live ? at::empty(sh, fopt) : at::zeros(sh, fopt);
     };
-    Tensor g_means3D = out({n, P, 3}), g_means2D = has_m2d ? out({NV, P, 3}) : Tensor(), g_op = out({n, P, 1});
-    Tensor g_shs = shs.defined() ? out({n, P, M, 3}) : Tensor();
-    Tensor g_col = has_colors ? out({n, P, 3}) : Tensor();
-    Tensor g_scales = scales.defined() ? out({n, P, 3}) : Tensor();
-    Tensor g_rots = scales.defined() ? out({n, P, 4}) : Tensor();
-    Tensor g_cov = cov.defined() ? out({n, P, 6}) : Tensor();
+    Tensor g_means3D = out(false, {3}), g_means2D = has_m2d ? out(true, {3}) : Tensor(), g_op = out(false, {1});
+    Tensor g_shs = shs.defined() ? out(false, {M, 3}) : Tensor();
+    Tensor g_col = has_colors ? out(false, {3}) : Tensor();
+    Tensor g_scales = scales.defined() ? out(false, {3}) : Tensor();
+    Tensor g_rots = scales.defined() ? out(false, {4}) : Tensor();
+    Tensor g_cov = cov.defined() ? out(false, {6}) : Tensor();
     if (live) {
       void* stream = current_stream(dev);
       const WsKey key{(int)dev.index(), stream, &plan};
       auto [scratch, clean] = workspace_acquire(key, fopt.dtype(at::kByte));
       u3d_raster_desc dd = plan.d;
+      dd.item_offsets = ragged ? offsets.data_ptr<int32_t>() : nullptr;
       if (clean) dd.flags |= U3D_FLAG_ACC_CLEAN;
       const char* base = (const char*)arena.data_ptr();
       const int rc = u3d_rasterize_backward(&dd, fptr(bg), fptr(means3D), fptr(shs), fptr(colors), fptr(opac), fptr(scales), fptr(rots),
@@ -186,7 +212,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
       workspace_release(key, scratch);
     }
     return {g_means3D, g_means2D, g_shs, g_col, g_op, g_scales, g_rots, g_cov, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
-            Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+            Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -202,12 +228,13 @@ std::tuple<Tensor, Tensor, Tensor> rasterize_batched(const Tensor& means3D, cons
                                                      const c10::optional<Tensor>& rots, const c10::optional<Tensor>& cov, const Tensor& view,
                                                      const Tensor& proj, const Tensor& campos, const Tensor& bg, int64_t n_items, int64_t vpi,
                                                      int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier,
-                                                     int64_t sh_degree, int64_t flags) {
+                                                     int64_t sh_degree, int64_t flags, const c10::optional<Tensor>& item_offsets,
+                                                     int64_t max_P) {
   const c10::Device dev = means3D.device();
   auto f = [&](const c10::optional<Tensor>& t) { return opt(t, dev); };
   auto r = RasterizeFn::apply(f32c(means3D, dev), f(means2D), f(shs), f(colors), f32c(opac, dev), f(scales), f(rots), f(cov), f32c(view, dev),
                               f32c(proj, dev), f32c(campos, dev), f32c(bg, dev), n_items, vpi, H, W, tanfovx, tanfovy, scale_modifier, sh_degree,
-                              flags, false);
+                              flags, false, item_offsets, max_P);
   return {r[0], r[1], r[2]};
 }
 
@@ -222,7 +249,7 @@ std::tuple<Tensor, Tensor, Tensor> rasterize_view(const Tensor& means3D, const c
   auto f = [&](const c10::optional<Tensor>& t) { return opt(t, dev); };
   auto r = RasterizeFn::apply(f32c(means3D, dev), f(means2D), f(shs), f(colors), f32c(opac, dev), f(scales), f(rots), f(cov), f32c(view, dev),
                               f32c(proj, dev), f32c(campos, dev), f32c(bg, dev), 1, 1, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, flags,
-                              true);
+                              true, c10::nullopt, 0);
   return {r[0], r[1], r[2]};
 }
 
@@ -231,7 +258,11 @@ std::tuple<Tensor, Tensor, Tensor> rasterize_view(const Tensor& means3D, const c
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "torch binding of libunipre3d_rasterizer.so (include/unipre3d_rasterizer.h)";
   m.def("rasterize_view", &rasterize_view, "one view: the reference's per-view operator call");
-  m.def("rasterize_batched", &rasterize_batched, "n_items sets x views_per_item cameras in one launch sequence");
+  m.def("rasterize_batched", &rasterize_batched, "n_items sets x views_per_item cameras in one launch sequence",
+        py::arg("means3D"), py::arg("means2D"), py::arg("shs"), py::arg("colors_precomp"), py::arg("opacities"), py::arg("scales"),
+        py::arg("rotations"), py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("campos"), py::arg("bg"),
+        py::arg("n_items"), py::arg("views_per_item"), py::arg("H"), py::arg("W"), py::arg("tanfovx"), py::arg("tanfovy"),
+        py::arg("scale_modifier"), py::arg("sh_degree"), py::arg("flags"), py::arg("item_offsets") = py::none(), py::arg("max_P") = 0);
   m.def("abi_version", []() { return u3d_abi_version(); });
   m.def("clear_workspaces", []() { std::lock_guard<std::mutex> lock(g_ws_mu); g_ws.clear(); },
         "drop the cached backward scratch buffers (the next backward of every shape clears its accumulators itself)");

@@ -20,12 +20,12 @@ from .rasterizer import _Plan, _f32c, _stream_ptr
 class _RenderLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, head_out, center, viewmatrix, projmatrix, campos, gt, bg, H, W, tanfov, mode, offset_scale, sh_degree,
-                loss_kind, non_bg_rate, bg_rate, scale_modifier, flags):
+                loss_kind, non_bg_rate, bg_rate, scale_modifier, flags, isotropic, item_offsets, max_P):
         lib = _lib.load()
         dev = head_out.device
         if dev.type != "cuda":
             raise RuntimeError("the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback")
-        B, P, C = head_out.shape
+        B, P, C, total_P = _batch_shape(head_out, item_offsets, max_P)
         NV = viewmatrix.shape[0]
         if B == 0 or NV % B != 0:
             raise ValueError(f"{NV} cameras for {B} Gaussian sets: every set needs the same number of views")
@@ -33,21 +33,22 @@ class _RenderLossFn(torch.autograd.Function):
         K = (sh_degree + 1) ** 2
         if C != 11 + 3 * K:
             raise ValueError(f"head output has {C} channels, expected {11 + 3 * K} for SH degree {sh_degree}")
-        plan = _Plan(B, V, P, H, W, tanfov, tanfov, scale_modifier, sh_degree, K, flags)
-        hd = _lib.HeadDesc(mode, C, offset_scale)
+        plan = _Plan(B, V, P, H, W, tanfov, tanfov, scale_modifier, sh_degree, K, flags, total_P=total_P)
+        desc = plan.with_offsets(item_offsets)
+        hd = _lib.HeadDesc(mode, C, offset_scale, int(bool(isotropic)))
         ld = _lib.LossDesc(_lib.LOSS_KINDS[loss_kind], non_bg_rate, bg_rate)
         color = torch.empty((NV, 3, H, W), dtype=torch.float32, device=dev)
-        radii = torch.zeros((NV, P), dtype=torch.int32, device=dev)
+        radii = torch.zeros((V * total_P,) if total_P else (NV, P), dtype=torch.int32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
         geom, binning, image, fused = u8(plan.sizes.geom_bytes), u8(plan.sizes.binning_bytes), u8(plan.sizes.image_bytes), \
             u8(plan.sizes.fused_bytes)
         p = _lib.ptr
-        rc = lib.u3d_render_loss_forward(ctypes.byref(plan.desc), ctypes.byref(hd), ctypes.byref(ld), p(bg), p(head_out), p(center),
+        rc = lib.u3d_render_loss_forward(ctypes.byref(desc), ctypes.byref(hd), ctypes.byref(ld), p(bg), p(head_out), p(center),
                                          p(viewmatrix), p(projmatrix), p(campos), p(gt), p(color), p(radii), p(loss), p(geom),
                                          p(binning), p(image), p(fused), _stream_ptr(dev))
         _lib.check(rc, "u3d_render_loss_forward")
-        ctx.plan, ctx.hd, ctx.ld = plan, hd, ld
+        ctx.plan, ctx.hd, ctx.ld, ctx.desc, ctx.item_offsets = plan, hd, ld, desc, item_offsets
         ctx.save_for_backward(head_out, center, viewmatrix, projmatrix, campos, gt, bg, color, radii, geom, binning, image, fused)
         ctx.mark_non_differentiable(radii)     # `color` stays differentiable: an image-space term (LPIPS) may hang off it
         ctx.set_materialize_grads(False)
@@ -59,7 +60,7 @@ class _RenderLossFn(torch.autograd.Function):
         head_out, center, viewmatrix, projmatrix, campos, gt, bg, color, radii, geom, binning, image, fused = ctx.saved_tensors
         dev = head_out.device
         if grad_loss is None and grad_color is None:
-            return (torch.zeros_like(head_out),) + (None,) * 17
+            return (torch.zeros_like(head_out),) + (None,) * 20
         d_head = torch.empty_like(head_out)
         scratch = torch.empty(ctx.plan.sizes.backward_bytes, dtype=torch.uint8, device=dev)
         dloss = _f32c(grad_loss, dev).reshape(1) if grad_loss is not None else torch.zeros(1, dtype=torch.float32, device=dev)
@@ -69,11 +70,11 @@ class _RenderLossFn(torch.autograd.Function):
                 raise RuntimeError(f"gradient of the rendered images has shape {tuple(grad_color.shape)}, expected {tuple(color.shape)}")
             extra = _f32c(grad_color, dev)
         p = _lib.ptr
-        rc = lib.u3d_render_loss_backward(ctypes.byref(ctx.plan.desc), ctypes.byref(ctx.hd), ctypes.byref(ctx.ld), p(bg), p(head_out),
+        rc = lib.u3d_render_loss_backward(ctypes.byref(ctx.desc), ctypes.byref(ctx.hd), ctypes.byref(ctx.ld), p(bg), p(head_out),
                                           p(center), p(viewmatrix), p(projmatrix), p(campos), p(gt), p(radii), p(color), p(dloss), p(extra),
                                           p(geom), p(binning), p(image), p(fused), p(scratch), p(d_head), _stream_ptr(dev))
         _lib.check(rc, "u3d_render_loss_backward")
-        return (d_head,) + (None,) * 17
+        return (d_head,) + (None,) * 20
 
 
 class _RenderLossStepFn(torch.autograd.Function):
@@ -82,23 +83,23 @@ class _RenderLossStepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, head_out, center, viewmatrix, projmatrix, campos, gt, bg, H, W, tanfov, mode, offset_scale, sh_degree,
-                loss_kind, non_bg_rate, bg_rate, scale_modifier, flags, want_color):
+                loss_kind, non_bg_rate, bg_rate, scale_modifier, flags, want_color, isotropic, item_offsets, max_P):
         lib = _lib.load()
         dev = head_out.device
         if dev.type != "cuda":
             raise RuntimeError("the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback")
-        B, P, C = head_out.shape
+        B, P, C, total_P = _batch_shape(head_out, item_offsets, max_P)
         NV = viewmatrix.shape[0]
         if B == 0 or NV % B != 0:
             raise ValueError(f"{NV} cameras for {B} Gaussian sets: every set needs the same number of views")
         K = (sh_degree + 1) ** 2
         if C != 11 + 3 * K:
             raise ValueError(f"head output has {C} channels, expected {11 + 3 * K} for SH degree {sh_degree}")
-        plan = _Plan(B, NV // B, P, H, W, tanfov, tanfov, scale_modifier, sh_degree, K, flags)
-        hd = _lib.HeadDesc(mode, C, offset_scale)
+        plan = _Plan(B, NV // B, P, H, W, tanfov, tanfov, scale_modifier, sh_degree, K, flags, total_P=total_P)
+        hd = _lib.HeadDesc(mode, C, offset_scale, int(bool(isotropic)))
         ld = _lib.LossDesc(_lib.LOSS_KINDS[loss_kind], non_bg_rate, bg_rate)
         color = torch.empty((NV, 3, H, W), dtype=torch.float32, device=dev) if want_color else None
-        radii = torch.empty((NV, P), dtype=torch.int32, device=dev)
+        radii = torch.empty(((NV // B) * total_P,) if total_P else (NV, P), dtype=torch.int32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         d_head = torch.empty_like(head_out)
         u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
@@ -106,12 +107,14 @@ class _RenderLossStepFn(torch.autograd.Function):
         # The backward scratch is kept between steps (per device, stream and size): a step leaves its gradient accumulators zero,
         # so the next one is told not to clear them again (U3D_FLAG_ACC_CLEAN; 80 bytes per (view, Gaussian) pair at scene level).
         sp = _stream_ptr(dev)
-        ws = _workspace(dev, sp, plan.sizes.backward_bytes, (B, NV // B, P, H, W, K))
+        # (a ragged batch lays its accumulators out by the sets' sizes: the promise only carries over to the same offsets tensor)
+        ws = _workspace(dev, sp, plan.sizes.backward_bytes, (B, NV // B, P, H, W, K, total_P, item_offsets.data_ptr() if total_P else 0))
         if ws[1]:
-            plan = _Plan(B, NV // B, P, H, W, tanfov, tanfov, scale_modifier, sh_degree, K, flags | _lib.FLAG_ACC_CLEAN)
+            plan = _Plan(B, NV // B, P, H, W, tanfov, tanfov, scale_modifier, sh_degree, K, flags | _lib.FLAG_ACC_CLEAN, total_P=total_P)
         ws[1] = False                     # (stays false if the call below raises)
+        desc = plan.with_offsets(item_offsets)
         p = _lib.ptr
-        rc = lib.u3d_render_loss_step(ctypes.byref(plan.desc), ctypes.byref(hd), ctypes.byref(ld), p(bg), p(head_out), p(center),
+        rc = lib.u3d_render_loss_step(ctypes.byref(desc), ctypes.byref(hd), ctypes.byref(ld), p(bg), p(head_out), p(center),
                                       p(viewmatrix), p(projmatrix), p(campos), p(gt), p(color), p(radii), p(loss), p(d_head),
                                       p(geom), p(binning), p(fused), p(ws[0]), sp)
         _lib.check(rc, "u3d_render_loss_step")
@@ -127,11 +130,28 @@ class _RenderLossStepFn(torch.autograd.Function):
     def backward(ctx, grad_loss, _gc, _gr):
         (d_head,) = ctx.saved_tensors
         if grad_loss is None:
-            return (torch.zeros_like(d_head),) + (None,) * 18
+            return (torch.zeros_like(d_head),) + (None,) * 21
         unit = _UNIT.get(d_head.device)
         if unit is not None and grad_loss.data_ptr() == unit.data_ptr():
-            return (d_head,) + (None,) * 18      # dL/dloss is THE unit tensor of backward_unit(): nothing to scale
-        return (d_head * grad_loss,) + (None,) * 18
+            return (d_head,) + (None,) * 21      # dL/dloss is THE unit tensor of backward_unit(): nothing to scale
+        return (d_head * grad_loss,) + (None,) * 21
+
+
+def _batch_shape(head_out, item_offsets, max_P):
+    """(sets, Gaussians per set | largest set, channels, total Gaussians of a ragged batch | 0)."""
+    if item_offsets is None:
+        if head_out.dim() != 3:
+            raise ValueError("head_out must be (B, P, C); pass item_offsets for a packed ragged batch (sum P_i, C)")
+        B, P, C = head_out.shape
+        return B, P, C, 0
+    if head_out.dim() != 2:
+        raise ValueError("ragged batch: head_out must be packed (sum P_i, C)")
+    if item_offsets.dtype != torch.int32 or item_offsets.device != head_out.device or not item_offsets.is_contiguous():
+        raise ValueError("item_offsets must be a contiguous int32 tensor on the Gaussians' device")
+    total, C = head_out.shape
+    if not max_P or max_P > total:
+        raise ValueError("ragged batch: max_P (the largest set) is required")
+    return item_offsets.numel() - 1, int(max_P), C, total
 
 
 _UNIT = {}
@@ -166,7 +186,8 @@ def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: 
                       level: str = "object", offset_scale: float = 1.0, max_sh_degree: int = 1, loss_kind: str = "focal_l2",
                       non_bg_color_loss_rate: float = 4.0, bg_color_loss_rate: float = 1.0, input_images: int = 0,
                       scaling_modifier: float = 1.0, antialiasing: bool = True, debug: bool = False,
-                      single_pass: bool = True, return_images: bool = True, differentiable_images: bool = False):
+                      single_pass: bool = True, return_images: bool = True, differentiable_images: bool = False,
+                      isotropic: bool = False, item_offsets: torch.Tensor = None, max_P: int = 0):
     """head_out (B,P,C) point-major raw head output (C = 23 at SH degree 1), center (B,P,3), cameras (B,Vtot,...),
     gt (B,Vtot,3,H,W).  Returns (loss scalar, rendered (B*V',3,H,W), radii (B*V',P)).
     single_pass (default): when a gradient is wanted, forward and backward run as ONE launch sequence
@@ -175,9 +196,13 @@ def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: 
     differentiable_images=True: the objective has a further image-space term -- the reference's
     `l12 + lambda_lpips * lpips(rendered, gt)` after `start_lpips_after` iterations (train_network.py:284-300).  The call then
     takes the two-pass route, the returned images carry gradient, and `(loss + lam * g(rendered)).backward()` adds
-    dL/d(rendered) to the in-kernel loss seed (u3d_render_loss_backward's dL_dcolor_extra): still one launch sequence each way."""
+    dL/d(rendered) to the in-kernel loss seed (u3d_render_loss_backward's dL_dcolor_extra): still one launch sequence each way.
+    isotropic: cfg.model.isotropic (the first scaling channel serves all three axes, model/gaussian_predictor.py:308-310).
+    Ragged batches (the scene-level branch's per-item lists, model/gaussian_predictor.py:331-364): head_out (sum P_i, C) and center
+    (sum P_i, 3) PACKED in set order, item_offsets int32 (B+1,) prefix sums on the device (rasterizer.pack_ragged), max_P the largest
+    set; radii then come back packed (V' * sum P_i,) -- one launch sequence for sets of different sizes."""
     dev = head_out.device
-    B = head_out.shape[0]
+    B = head_out.shape[0] if item_offsets is None else item_offsets.numel() - 1
     wv, fp, cc = world_view[:, input_images:], full_proj[:, input_images:], camera_center[:, input_images:]
     NV = B * wv.shape[1]
     t = math.tan(fov_deg * math.pi / 360)
@@ -190,9 +215,10 @@ def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: 
                                        f(gt[:, input_images:]).reshape(NV, 3, H, W), f(bg).reshape(3), int(H), int(W), float(t),
                                        1 if level == "object" else 2, float(offset_scale), int(max_sh_degree), loss_kind,
                                        float(non_bg_color_loss_rate), float(bg_color_loss_rate), float(scaling_modifier), flags,
-                                       bool(return_images))
+                                       bool(return_images), bool(isotropic), item_offsets, int(max_P))
     loss, img, radii = _RenderLossFn.apply(f(head_out), f(center), f(wv).reshape(NV, 16), f(fp).reshape(NV, 16), f(cc).reshape(NV, 3),
                                            f(gt[:, input_images:]).reshape(NV, 3, H, W), f(bg).reshape(3), int(H), int(W), float(t),
                                            1 if level == "object" else 2, float(offset_scale), int(max_sh_degree), loss_kind,
-                                           float(non_bg_color_loss_rate), float(bg_color_loss_rate), float(scaling_modifier), flags)
+                                           float(non_bg_color_loss_rate), float(bg_color_loss_rate), float(scaling_modifier), flags,
+                                           bool(isotropic), item_offsets, int(max_P))
     return loss, (img if differentiable_images else img.detach()), radii

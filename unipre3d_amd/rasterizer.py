@@ -54,23 +54,48 @@ def _none_if_empty(t):
 
 
 class _Plan:
-    """Descriptor + scratch sizes for one call shape (cached: the per-view drop-in route calls this B*V times a step)."""
+    """Descriptor + scratch sizes for one call shape (cached).  Ragged batches (total_P > 0) share the sizes of their
+    (n_items, views, largest set, total) shape; the device pointer to the prefix sums is set per call (`with_offsets`)."""
     _cache = {}
 
-    def __new__(cls, *key):
-        hit = cls._cache.get(key)
+    def __new__(cls, *key, total_P=0):
+        ck = key + (int(total_P),)
+        hit = cls._cache.get(ck)
         if hit is not None:
             return hit
         self = super().__new__(cls)
         self.desc = _lib.RasterDesc(*key)
+        self.desc.total_P = int(total_P)
+        probe = _lib.RasterDesc(*key)
+        probe.total_P = int(total_P)
+        probe.item_offsets = 8 if total_P else None          # (the size query only looks at whether it is set)
         self.sizes = _lib.ScratchSizes()
-        _lib.check(_lib.load().u3d_scratch_query(ctypes.byref(self.desc), ctypes.byref(self.sizes)), "u3d_scratch_query")
+        _lib.check(_lib.load().u3d_scratch_query(ctypes.byref(probe), ctypes.byref(self.sizes)), "u3d_scratch_query")
         if len(cls._cache) < 256:
-            cls._cache[key] = self
+            cls._cache[ck] = self
         return self
 
-    def __init__(self, n_items, vpi, P, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, M, flags):
+    def __init__(self, n_items, vpi, P, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, M, flags, total_P=0):
         pass
+
+    def with_offsets(self, item_offsets: Optional[torch.Tensor]) -> "_lib.RasterDesc":
+        """The descriptor of this call: a copy carrying the device pointer of `item_offsets` (int32, n_items + 1)."""
+        if not self.desc.total_P:
+            return self.desc
+        d = _lib.RasterDesc.from_buffer_copy(self.desc)
+        d.item_offsets = item_offsets.data_ptr()
+        return d
+
+
+def pack_ragged(tensors, device=None):
+    """Per-item list of (P_i, ...) tensors -> (packed (sum P_i, ...), item_offsets int32 (n+1,) on the device, sizes list).
+    The reference's scene-level branch hands its Gaussians over as such lists (model/gaussian_predictor.py:331-364)."""
+    sizes = [int(t.shape[0]) for t in tensors]
+    off = [0]
+    for n in sizes:
+        off.append(off[-1] + n)
+    dev = device if device is not None else tensors[0].device
+    return torch.cat(list(tensors), dim=0), torch.tensor(off, dtype=torch.int32, device=dev), sizes
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -133,13 +158,16 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 def rasterize_gaussians_batched(means3D, opacities, viewmatrix, projmatrix, campos, bg, image_height, image_width, tanfovx,
                                 tanfovy, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
                                 sh_degree=0, scale_modifier=1.0, antialiasing=True, debug=False, exact_aa_grad=False,
-                                means2D=None):
+                                means2D=None, item_offsets=None, max_P=0):
     """B sets x V cameras in ONE launch sequence.
     means3D (B,P,3), opacities (B,P,1), shs (B,P,M,3) | colors_precomp (B,P,3), scales (B,P,3) + rotations (B,P,4) |
     cov3D_precomp (B,P,6); viewmatrix/projmatrix (B,V,4,4), campos (B,V,3), bg (3,).
     means2D (B*V,P,3), optional: the per-view screen-space gradient sink (`viewspace_points` of
     gaussian_renderer/__init__.py:29); its .grad receives dL/dmean2D.
-    Returns color (B,V,3,H,W), radii (B,V,P) int32, invdepth (B,V,1,H,W)."""
+    Returns color (B,V,3,H,W), radii (B,V,P) int32, invdepth (B,V,1,H,W).
+    Ragged batch (item_offsets int32 (B+1,) on the device, max_P = largest set; see `pack_ragged`): every per-Gaussian tensor is
+    PACKED (sum P_i, ...) in set order; radii come back packed (V * sum P_i,), the pairs of set i and view v starting at
+    V * item_offsets[i] + v * P_i (`split_ragged_radii`), means2D is (V * sum P_i, 3) in the same layout."""
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
     if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -149,16 +177,28 @@ def rasterize_gaussians_batched(means3D, opacities, viewmatrix, projmatrix, camp
     if dev.type != "cuda":
         raise RuntimeError("the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback "
                            "(the CPU restatement lives in oracle/ and is test infrastructure only)")
-    B, P = means3D.shape[0], means3D.shape[1]
+    ragged = item_offsets is not None
+    B = item_offsets.numel() - 1 if ragged else means3D.shape[0]
+    P = int(max_P) if ragged else means3D.shape[1]
     V = viewmatrix.shape[1]
     flags = (_lib.FLAG_ANTIALIASING if antialiasing else 0) | (_lib.FLAG_DEBUG if debug else 0) | \
         (_lib.FLAG_EXACT_AA_GRAD if exact_aa_grad else 0)
     color, radii, invdepth = _C().rasterize_batched(
-        means3D, means2D, shs, colors_precomp, opacities.reshape(B, P, 1), scales, rotations, cov3D_precomp,
-        viewmatrix.reshape(B * V, 16), projmatrix.reshape(B * V, 16), campos.reshape(B * V, 3), bg.reshape(3), B, V, int(image_height),
-        int(image_width), float(tanfovx), float(tanfovy), float(scale_modifier), int(sh_degree), flags)
-    return (color.reshape(B, V, 3, image_height, image_width), radii.reshape(B, V, P),
+        means3D, means2D, shs, colors_precomp, opacities.reshape(-1, 1) if ragged else opacities.reshape(B, P, 1), scales, rotations,
+        cov3D_precomp, viewmatrix.reshape(B * V, 16), projmatrix.reshape(B * V, 16), campos.reshape(B * V, 3), bg.reshape(3), B, V,
+        int(image_height), int(image_width), float(tanfovx), float(tanfovy), float(scale_modifier), int(sh_degree), flags,
+        item_offsets, P if ragged else 0)
+    return (color.reshape(B, V, 3, image_height, image_width), radii if ragged else radii.reshape(B, V, P),
             invdepth.reshape(B, V, 1, image_height, image_width))
+
+
+def split_ragged_radii(radii: torch.Tensor, sizes, V: int):
+    """Packed (V * sum P_i,) per-(view, Gaussian) values of a ragged call -> list of per-set (V, P_i, ...) views."""
+    out, o = [], 0
+    for n in sizes:
+        out.append(radii[V * o: V * (o + n)].reshape(V, n, *radii.shape[1:]))
+        o += n
+    return out
 
 
 class GaussianRasterizer(nn.Module):
