@@ -101,8 +101,10 @@ def test_ragged_fused_step_equals_one_call_per_set(sizes, level, kind, single_pa
         o = 0
         for i, n in enumerate(sizes):
             assert torch.equal(img[i * V:(i + 1) * V], ref_img[i]), (rnd, i)
-            a, b_ = hp.grad[o:o + n] * B, ref_grad[i]            # the packed loss averages over B times as many pixels
-            assert rel_l2(a.cpu().numpy(), b_.cpu().numpy()) < 2e-6, (rnd, i, rel_l2(a.cpu().numpy(), b_.cpu().numpy()))
+            # the packed loss averages over B times as many pixels: every seed is scaled by 1/B in-kernel, i.e. every term of the
+            # gradient sum is re-rounded (scene-level sums cancel ~1000x, so that alone moves the fp32 result by a few 1e-6)
+            a, b_ = hp.grad[o:o + n] * B, ref_grad[i]
+            assert rel_l2(a.cpu().numpy(), b_.cpu().numpy()) < 2e-5, (rnd, i, rel_l2(a.cpu().numpy(), b_.cpu().numpy()))
             o += n
 
 
