@@ -311,6 +311,8 @@ def test_single_pass_step_reuses_its_workspace_with_clean_accumulators(level, P,
         torch.cuda.synchronize()
         return loss.detach().clone(), h.grad.clone()
 
+    from unipre3d_amd import rasterizer
+    C = rasterizer._C()
     batches = []
     for seed in (3, 4, 5):
         _, bd = _batch(2, P, V, H, W, level=level, seed=seed)
@@ -319,15 +321,15 @@ def test_single_pass_step_reuses_its_workspace_with_clean_accumulators(level, P,
         batches.append(bd)
     fresh = []
     for bd in batches:
-        fused._WS.clear()
+        C.clear_workspaces()
         fresh.append(step(bd))
-        assert any(ws[1] for ws in fused._WS.values())           # the step left its workspace marked clean
-    fused._WS.clear()
+        assert C.workspaces() == (1, 1)                          # the step left its workspace marked clean
+    C.clear_workspaces()
     for rnd in range(2):
         for bd, (l0, g0) in zip(batches, fresh):
             l1, g1 = step(bd)                                    # from the second step on: U3D_FLAG_ACC_CLEAN
             assert torch.equal(l1, l0) and torch.equal(g1, g0), (rnd, float((g1 - g0).abs().max()))
-    assert len(fused._WS) == 1
+    assert C.workspaces() == (1, 1)
 
 
 @pytest.mark.parametrize("level,loss_kind,P,V,H,W", [("object", "focal_l2", 128, 4, 96, 96), ("scene", "l2", 600, 2, 48, 80)])

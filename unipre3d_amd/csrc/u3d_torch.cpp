@@ -57,7 +57,7 @@ const Plan& plan_for(const u3d_raster_desc& d) {
 // per call.  Calls on one stream are ordered, so one scratch per stream is enough; `clean` is dropped while a call is in flight on
 // the host so that a failed call cannot leave a stale promise behind.
 struct Workspace { Tensor buf; bool clean = false; };
-using WsKey = std::tuple<int, void*, const Plan*>;
+using WsKey = std::tuple<int, void*, const Plan*, const void*>;   // device, stream, shape, ragged layout (offsets pointer) or null
 std::mutex g_ws_mu;
 std::map<WsKey, Workspace> g_ws;
 // takes the scratch of `key` (allocating it on first use) and withdraws its promise; returns whether the promise held
@@ -197,7 +197,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     Tensor g_cov = cov.defined() ? out(false, {6}) : Tensor();
     if (live) {
       void* stream = current_stream(dev);
-      const WsKey key{(int)dev.index(), stream, &plan};
+      const WsKey key{(int)dev.index(), stream, &plan, ragged ? (const void*)offsets.data_ptr() : nullptr};
       auto [scratch, clean] = workspace_acquire(key, fopt.dtype(at::kByte));
       u3d_raster_desc dd = plan.d;
       dd.item_offsets = ragged ? offsets.data_ptr<int32_t>() : nullptr;
@@ -215,6 +215,110 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
             Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
+
+// ---- fused render-loss training step (u3d_render_loss_step): activations + render + loss + backward in one launch sequence ------
+// One call per training step, but its host cost is exposed whenever a step's kernels are short (C1, C3: 7 launches in ~0.1 ms).
+std::mutex g_unit_mu;
+std::map<int, Tensor> g_unit;
+Tensor unit_tensor(int64_t device_index) {   // the cached dL/dloss = 1 of fused.backward_unit(): recognised by its storage in backward
+  std::lock_guard<std::mutex> lock(g_unit_mu);
+  auto it = g_unit.find((int)device_index);
+  if (it == g_unit.end())
+    it = g_unit.emplace((int)device_index, at::ones({}, at::TensorOptions().dtype(at::kFloat).device(c10::Device(c10::kCUDA, (c10::DeviceIndex)device_index)))).first;
+  return it->second;
+}
+
+struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
+  using OptTensor = c10::optional<Tensor>;
+  static variable_list forward(AutogradContext* ctx, Tensor head_out, Tensor center, Tensor view, Tensor proj, Tensor campos, Tensor gt,
+                               Tensor bg, int64_t H, int64_t W, double tanfov, int64_t mode, double offset_scale, int64_t sh_degree,
+                               int64_t loss_kind, double non_bg_rate, double bg_rate, double scale_modifier, int64_t flags, bool want_color,
+                               bool isotropic, OptTensor item_offsets_, int64_t max_P) {
+    const c10::Device dev = head_out.device();
+    TORCH_CHECK(dev.is_cuda(), "the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback");
+    const bool ragged = item_offsets_.has_value() && item_offsets_->defined();
+    Tensor offsets;
+    int64_t B, P, C, total_P = 0;
+    if (ragged) {
+      offsets = *item_offsets_;
+      TORCH_CHECK(head_out.dim() == 2, "ragged batch: head_out must be packed (sum P_i, C)");
+      TORCH_CHECK(offsets.device() == dev && offsets.scalar_type() == at::kInt && offsets.is_contiguous(),
+                  "item_offsets must be a contiguous int32 tensor on the Gaussians' device");
+      B = offsets.numel() - 1; total_P = head_out.size(0); C = head_out.size(1); P = max_P;
+      TORCH_CHECK(P > 0 && P <= total_P, "ragged batch: max_P (the largest set) is required");
+    } else {
+      TORCH_CHECK(head_out.dim() == 3, "head_out must be (B, P, C); pass item_offsets for a packed ragged batch (sum P_i, C)");
+      B = head_out.size(0); P = head_out.size(1); C = head_out.size(2);
+    }
+    const int64_t NV = view.size(0), K = (sh_degree + 1) * (sh_degree + 1);
+    TORCH_CHECK(B > 0 && NV % B == 0, NV, " cameras for ", B, " Gaussian sets: every set needs the same number of views");
+    TORCH_CHECK(C == 11 + 3 * K, "head output has ", C, " channels, expected ", 11 + 3 * K, " for SH degree ", sh_degree);
+    const int64_t V = NV / B;
+    u3d_raster_desc d{};
+    d.n_items = (int32_t)B; d.views_per_item = (int32_t)V; d.P = (int32_t)P; d.image_height = (int32_t)H; d.image_width = (int32_t)W;
+    d.tanfovx = d.tanfovy = (float)tanfov; d.scale_modifier = (float)scale_modifier; d.sh_degree = (int32_t)sh_degree;
+    d.sh_coeffs = (int32_t)K; d.flags = (int32_t)flags; d.total_P = (int32_t)total_P;
+    d.item_offsets = ragged ? (const int32_t*)8 : nullptr;
+    const Plan& plan = plan_for(d);
+    u3d_head_desc hd{(int32_t)mode, (int32_t)C, (float)offset_scale, isotropic ? 1 : 0};
+    u3d_loss_desc ld{(int32_t)loss_kind, (float)non_bg_rate, (float)bg_rate};
+    const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+    Tensor color = want_color ? at::empty({NV, 3, H, W}, fopt) : at::empty({0}, fopt);
+    Tensor radii = ragged ? at::empty({V * total_P}, fopt.dtype(at::kInt)) : at::empty({NV, P}, fopt.dtype(at::kInt));
+    Tensor loss = at::empty({}, fopt);
+    Tensor d_head = at::empty_like(head_out);
+    const size_t o_fused = plan.o_image;                                 // arena: geom | binning | fused  (no image buffer in this path)
+    Tensor arena = at::empty({(int64_t)(o_fused + align256(plan.s.fused_bytes))}, fopt.dtype(at::kByte));
+    char* base = (char*)arena.data_ptr();
+    void* stream = current_stream(dev);
+    const WsKey key{(int)dev.index(), stream, &plan, ragged ? (const void*)offsets.data_ptr() : nullptr};
+    auto [scratch, clean] = workspace_acquire(key, fopt.dtype(at::kByte));
+    u3d_raster_desc dd = plan.d;
+    dd.item_offsets = ragged ? offsets.data_ptr<int32_t>() : nullptr;
+    if (clean) dd.flags |= U3D_FLAG_ACC_CLEAN;
+    const int rc = u3d_render_loss_step(&dd, &hd, &ld, fptr(bg), fptr(head_out), fptr(center), fptr(view), fptr(proj), fptr(campos), fptr(gt),
+                                        want_color ? color.data_ptr<float>() : nullptr, radii.data_ptr<int32_t>(), loss.data_ptr<float>(),
+                                        d_head.data_ptr<float>(), base, base + plan.o_binning, base + o_fused, scratch.data_ptr(), stream);
+    TORCH_CHECK(rc == U3D_OK, "u3d_render_loss_step failed: ", u3d_error_string(rc), " (code ", rc, ")");
+    workspace_release(key, scratch);
+    ctx->save_for_backward({d_head});
+    ctx->mark_non_differentiable({color, radii});
+    ctx->set_materialize_grads(false);
+    return {loss, color, radii};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const Tensor d_head = ctx->get_saved_variables()[0];
+    Tensor g;
+    if (!grads[0].defined()) g = at::zeros_like(d_head);
+    else {
+      Tensor unit;
+      {
+        std::lock_guard<std::mutex> lock(g_unit_mu);
+        auto it = g_unit.find((int)d_head.device().index());
+        if (it != g_unit.end()) unit = it->second;
+      }
+      // dL/dloss is THE unit tensor of fused.backward_unit(): nothing to scale (no ones_like fill, no d_head * 1 multiply)
+      g = (unit.defined() && grads[0].data_ptr() == unit.data_ptr()) ? d_head : d_head * grads[0];
+    }
+    variable_list out(22);
+    out[0] = g;
+    return out;
+  }
+};
+
+std::tuple<Tensor, Tensor, Tensor> render_loss_step(const Tensor& head_out, const Tensor& center, const Tensor& view, const Tensor& proj,
+                                                    const Tensor& campos, const Tensor& gt, const Tensor& bg, int64_t H, int64_t W, double tanfov,
+                                                    int64_t mode, double offset_scale, int64_t sh_degree, int64_t loss_kind, double non_bg_rate,
+                                                    double bg_rate, double scale_modifier, int64_t flags, bool want_color, bool isotropic,
+                                                    const c10::optional<Tensor>& item_offsets, int64_t max_P) {
+  const c10::Device dev = head_out.device();
+  const int64_t NV = view.numel() / 16;
+  auto r = RenderLossStepFn::apply(f32c(head_out, dev), f32c(center, dev), f32c(view, dev).reshape({NV, 16}), f32c(proj, dev).reshape({NV, 16}),
+                                   f32c(campos, dev).reshape({NV, 3}), f32c(gt, dev), f32c(bg, dev).reshape({3}), H, W, tanfov, mode, offset_scale,
+                                   sh_degree, loss_kind, non_bg_rate, bg_rate, scale_modifier, flags, want_color, isotropic, item_offsets, max_P);
+  return {r[0], r[1], r[2]};
+}
 
 // empty tensors count as absent (upstream's convention for colors_precomp / cov3D_precomp); present ones become contiguous fp32 on `dev`
 inline c10::optional<Tensor> opt(const c10::optional<Tensor>& t, const c10::Device& dev) {
@@ -263,6 +367,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("rotations"), py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("campos"), py::arg("bg"),
         py::arg("n_items"), py::arg("views_per_item"), py::arg("H"), py::arg("W"), py::arg("tanfovx"), py::arg("tanfovy"),
         py::arg("scale_modifier"), py::arg("sh_degree"), py::arg("flags"), py::arg("item_offsets") = py::none(), py::arg("max_P") = 0);
+  m.def("render_loss_step", &render_loss_step,
+        "fused training step (u3d_render_loss_step): loss, [images], radii; autograd's backward returns the stored d loss / d head_out");
+  m.def("unit_tensor", &unit_tensor, "the cached dL/dloss = 1 tensor of a device (fused.backward_unit)");
   m.def("abi_version", []() { return u3d_abi_version(); });
   m.def("clear_workspaces", []() { std::lock_guard<std::mutex> lock(g_ws_mu); g_ws.clear(); },
         "drop the cached backward scratch buffers (the next backward of every shape clears its accumulators itself)");

@@ -14,7 +14,7 @@ import math
 import torch
 
 from . import _lib
-from .rasterizer import _Plan, _f32c, _stream_ptr
+from .rasterizer import _C, _Plan, _f32c, _stream_ptr
 
 
 class _RenderLossFn(torch.autograd.Function):
@@ -77,66 +77,6 @@ class _RenderLossFn(torch.autograd.Function):
         return (d_head,) + (None,) * 20
 
 
-class _RenderLossStepFn(torch.autograd.Function):
-    """Training form: ONE launch sequence computes the loss and d loss / d head_out (u3d_render_loss_step); autograd's
-    backward only scales the stored gradient by dL/dloss."""
-
-    @staticmethod
-    def forward(ctx, head_out, center, viewmatrix, projmatrix, campos, gt, bg, H, W, tanfov, mode, offset_scale, sh_degree,
-                loss_kind, non_bg_rate, bg_rate, scale_modifier, flags, want_color, isotropic, item_offsets, max_P):
-        lib = _lib.load()
-        dev = head_out.device
-        if dev.type != "cuda":
-            raise RuntimeError("the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback")
-        B, P, C, total_P = _batch_shape(head_out, item_offsets, max_P)
-        NV = viewmatrix.shape[0]
-        if B == 0 or NV % B != 0:
-            raise ValueError(f"{NV} cameras for {B} Gaussian sets: every set needs the same number of views")
-        K = (sh_degree + 1) ** 2
-        if C != 11 + 3 * K:
-            raise ValueError(f"head output has {C} channels, expected {11 + 3 * K} for SH degree {sh_degree}")
-        plan = _Plan(B, NV // B, P, H, W, tanfov, tanfov, scale_modifier, sh_degree, K, flags, total_P=total_P)
-        hd = _lib.HeadDesc(mode, C, offset_scale, int(bool(isotropic)))
-        ld = _lib.LossDesc(_lib.LOSS_KINDS[loss_kind], non_bg_rate, bg_rate)
-        color = torch.empty((NV, 3, H, W), dtype=torch.float32, device=dev) if want_color else None
-        radii = torch.empty(((NV // B) * total_P,) if total_P else (NV, P), dtype=torch.int32, device=dev)
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        d_head = torch.empty_like(head_out)
-        u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
-        geom, binning, fused = u8(plan.sizes.geom_bytes), u8(plan.sizes.binning_bytes), u8(plan.sizes.fused_bytes)
-        # The backward scratch is kept between steps (per device, stream and size): a step leaves its gradient accumulators zero,
-        # so the next one is told not to clear them again (U3D_FLAG_ACC_CLEAN; 80 bytes per (view, Gaussian) pair at scene level).
-        sp = _stream_ptr(dev)
-        # (a ragged batch lays its accumulators out by the sets' sizes: the promise only carries over to the same offsets tensor)
-        ws = _workspace(dev, sp, plan.sizes.backward_bytes, (B, NV // B, P, H, W, K, total_P, item_offsets.data_ptr() if total_P else 0))
-        if ws[1]:
-            plan = _Plan(B, NV // B, P, H, W, tanfov, tanfov, scale_modifier, sh_degree, K, flags | _lib.FLAG_ACC_CLEAN, total_P=total_P)
-        ws[1] = False                     # (stays false if the call below raises)
-        desc = plan.with_offsets(item_offsets)
-        p = _lib.ptr
-        rc = lib.u3d_render_loss_step(ctypes.byref(desc), ctypes.byref(hd), ctypes.byref(ld), p(bg), p(head_out), p(center),
-                                      p(viewmatrix), p(projmatrix), p(campos), p(gt), p(color), p(radii), p(loss), p(d_head),
-                                      p(geom), p(binning), p(fused), p(ws[0]), sp)
-        _lib.check(rc, "u3d_render_loss_step")
-        ws[1] = True
-        ctx.save_for_backward(d_head)
-        ctx.set_materialize_grads(False)
-        if color is None:
-            color = torch.empty(0, device=dev)
-        ctx.mark_non_differentiable(color, radii)
-        return loss, color, radii
-
-    @staticmethod
-    def backward(ctx, grad_loss, _gc, _gr):
-        (d_head,) = ctx.saved_tensors
-        if grad_loss is None:
-            return (torch.zeros_like(d_head),) + (None,) * 21
-        unit = _UNIT.get(d_head.device)
-        if unit is not None and grad_loss.data_ptr() == unit.data_ptr():
-            return (d_head,) + (None,) * 21      # dL/dloss is THE unit tensor of backward_unit(): nothing to scale
-        return (d_head * grad_loss,) + (None,) * 21
-
-
 def _batch_shape(head_out, item_offsets, max_P):
     """(sets, Gaussians per set | largest set, channels, total Gaussians of a ragged batch | 0)."""
     if item_offsets is None:
@@ -154,31 +94,12 @@ def _batch_shape(head_out, item_offsets, max_P):
     return item_offsets.numel() - 1, int(max_P), C, total
 
 
-_UNIT = {}
-_WS = {}   # (device index, stream, bytes, call shape) -> [uint8 tensor, accumulators known to be zero]
-
-
-def _workspace(dev: torch.device, stream, nbytes: int, shape):
-    # keyed by the call shape, not by the size: "accumulators are zero" is a statement about one scratch LAYOUT (another shape of
-    # the same total size puts its accumulators where this one keeps partial rows)
-    key = (torch.cuda.current_device(), getattr(stream, "value", stream), int(nbytes)) + tuple(shape)
-    ws = _WS.get(key)
-    if ws is None:
-        if len(_WS) >= 8:                  # shapes come and go (validation sizes, ragged last batch): keep the cache small
-            _WS.pop(next(iter(_WS)))
-        ws = _WS[key] = [torch.empty(int(nbytes), dtype=torch.uint8, device=dev), False]
-    return ws
-
-
 def backward_unit(loss: torch.Tensor) -> None:
     """`loss.backward()` for the loss of `render_loss_fused(single_pass=True)` when it is the quantity being minimised
     (dL/dloss = 1): seeds autograd with a cached read-only ones tensor, which the fused step recognises by its storage, so
     neither the `ones_like` fill nor the `d_head * 1` multiply is launched (two ~5 us kernels per step).  Any other use of the
     loss (scaled, summed with other terms) goes through `loss.backward()` as usual."""
-    unit = _UNIT.get(loss.device)
-    if unit is None:
-        unit = _UNIT[loss.device] = torch.ones((), dtype=torch.float32, device=loss.device)
-    torch.autograd.backward(loss, grad_tensors=(unit,))
+    torch.autograd.backward(loss, grad_tensors=(_C().unit_tensor(loss.device.index if loss.device.index is not None else torch.cuda.current_device()),))
 
 
 def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: torch.Tensor, full_proj: torch.Tensor,
@@ -211,11 +132,13 @@ def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: 
     if differentiable_images and not return_images:
         raise ValueError("differentiable_images=True needs return_images=True")
     if single_pass and not differentiable_images and head_out.requires_grad and torch.is_grad_enabled():
-        return _RenderLossStepFn.apply(f(head_out), f(center), f(wv).reshape(NV, 16), f(fp).reshape(NV, 16), f(cc).reshape(NV, 3),
-                                       f(gt[:, input_images:]).reshape(NV, 3, H, W), f(bg).reshape(3), int(H), int(W), float(t),
-                                       1 if level == "object" else 2, float(offset_scale), int(max_sh_degree), loss_kind,
-                                       float(non_bg_color_loss_rate), float(bg_color_loss_rate), float(scaling_modifier), flags,
-                                       bool(return_images), bool(isotropic), item_offsets, int(max_P))
+        # training form: ONE launch sequence computes the loss and d loss / d head_out (u3d_render_loss_step) behind a C++ autograd
+        # function (csrc/u3d_torch.cpp) whose backward only scales the stored gradient; it keeps the backward scratch per stream and
+        # shape and tells the library that the accumulators are still zero (U3D_FLAG_ACC_CLEAN)
+        return _C().render_loss_step(head_out, center, wv, fp, cc, gt[:, input_images:].reshape(NV, 3, H, W), bg, int(H), int(W), float(t),
+                                     1 if level == "object" else 2, float(offset_scale), int(max_sh_degree), _lib.LOSS_KINDS[loss_kind],
+                                     float(non_bg_color_loss_rate), float(bg_color_loss_rate), float(scaling_modifier), flags,
+                                     bool(return_images), bool(isotropic), item_offsets, int(max_P))
     loss, img, radii = _RenderLossFn.apply(f(head_out), f(center), f(wv).reshape(NV, 16), f(fp).reshape(NV, 16), f(cc).reshape(NV, 3),
                                            f(gt[:, input_images:]).reshape(NV, 3, H, W), f(bg).reshape(3), int(H), int(W), float(t),
                                            1 if level == "object" else 2, float(offset_scale), int(max_sh_degree), loss_kind,
