@@ -131,6 +131,12 @@ def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: 
     f = lambda x: _f32c(x, dev)
     if differentiable_images and not return_images:
         raise ValueError("differentiable_images=True needs return_images=True")
+    K = (int(max_sh_degree) + 1) ** 2
+    if head_out.shape[-1] != 11 + 3 * K:
+        raise ValueError(f"head output has {head_out.shape[-1]} channels, expected {11 + 3 * K} for SH degree {max_sh_degree}")
+    _batch_shape(head_out, item_offsets, max_P)          # (shape / dtype errors of a ragged batch as ValueError)
+    if B == 0 or NV % B != 0:
+        raise ValueError(f"{NV} cameras for {B} Gaussian sets: every set needs the same number of views")
     if single_pass and not differentiable_images and head_out.requires_grad and torch.is_grad_enabled():
         # training form: ONE launch sequence computes the loss and d loss / d head_out (u3d_render_loss_step) behind a C++ autograd
         # function (csrc/u3d_torch.cpp) whose backward only scales the stored gradient; it keeps the backward scratch per stream and
