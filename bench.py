@@ -54,18 +54,57 @@ def algorithmic_bytes(kind: str, P: int, R: float, T: int, HW: int) -> float:
     }[kind]
 
 
+PROFILE_ROUND = "r02"
+# measured instruction-class issue costs on gfx950, cycles per wave64 instruction per SIMD (profiles/r01/valu_instruction_classes.txt,
+# tools/ub/ops.hip under rocprofv3 --pmc): FMA / MUL / ADD / MOV 2.13, compare / min / select / DPP 4.08, exp / rcp 8.1; a scalar
+# instruction costs the SIMD's issue port about 1.7 (profiles/r01/ub_mixed_streams.txt: fma + s_and = 1.8 x an fma alone)
+ISSUE_CYCLES = {"fma_class": 2.13, "other_valu": 4.08, "trans": 8.1, "salu": 1.7}
+N_SIMD, SHADER_CLOCK_HZ = 1024, 2.4e9     # MI355X: 256 CUs x 4 SIMDs; MI355X_MICROARCH.md peak engine clock
+
+
+def _profile_json(name: str):
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, name)
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
 def pmc_traffic(kernel: str, config: str, default_path: bool):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01/pmc_traffic_C2_single_pass.json: separate
-    FETCH_SIZE / WRITE_SIZE runs of this very command, FETCH_SIZE doubled per the gfx950 calibration).  None when the
-    run does not match the profiled workload."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_C2_single_pass.json")
-    if config != "C2" or not default_path or not os.path.exists(path):
+    """HBM bytes per launch of the dominant tile kernel TOGETHER WITH the bwd_reduce kernel of its scope, from the committed PMC
+    passes (profiles/r02/pmc_traffic_<config>.json: separate FETCH_SIZE / WRITE_SIZE runs of this very command, FETCH_SIZE doubled
+    per the gfx950 calibration of MI355X_MICROARCH.md).  None when the run does not match a profiled workload."""
+    prof = _profile_json(f"pmc_traffic_{config}.json") if default_path else None
+    if not prof:
         return None
-    per = json.load(open(path))["per_launch"]
+    per = prof["per_launch"]
     key = {"render_fb": "render_fb_wave_kernel"}.get(kernel)
     if key not in per:
         return None
-    return per[key]["hbm_bytes_corrected"] + per.get("bwd_reduce_kernel", {}).get("hbm_bytes_corrected", 0.0)
+    reduce_bytes = sum(per[k]["hbm_bytes_corrected"] for k in ("bwd_reduce1_kernel", "bwd_reduce_kernel") if k in per)
+    return per[key]["hbm_bytes_corrected"] + reduce_bytes
+
+
+def issue_roofline(config: str, default_path: bool, measured_ms: float):
+    """The bound that actually binds the tile kernel: VALU / SALU ISSUE, not HBM.  From the committed SQ counter passes
+    (profiles/r02/sq_issue_<config>.json, tools/profile_r02.sh) the kernel's instruction counts per launch, split into the
+    measured issue classes; floor = sum(count x cycles per class) / (1024 SIMDs x clock).  `frac` = floor / measured duration of
+    the tile kernel alone (rocprofv3 average of the same profile).  Two floors are given: `lower` prices every non-transcendental
+    VALU instruction as an FMA (no kernel with this instruction COUNT can run faster), `by_class` prices add/mul/fma at 2.13,
+    transcendentals at 8.1 and the rest (compares, selects, min, DPP-carrying adds are undercounted here) at 4.08."""
+    prof = _profile_json(f"sq_issue_{config}.json") if default_path else None
+    if not prof:
+        return None
+    c = prof["per_launch"]
+    valu, salu, trans = c["SQ_INSTS_VALU"], c["SQ_INSTS_SALU"], c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+    fma = c.get("SQ_INSTS_VALU_FMA_F32", 0.0) + c.get("SQ_INSTS_VALU_MUL_F32", 0.0) + c.get("SQ_INSTS_VALU_ADD_F32", 0.0)
+    per = N_SIMD * SHADER_CLOCK_HZ
+    lower = ((valu - trans) * ISSUE_CYCLES["fma_class"] + trans * ISSUE_CYCLES["trans"] + salu * ISSUE_CYCLES["salu"]) / per
+    by_class = (fma * ISSUE_CYCLES["fma_class"] + trans * ISSUE_CYCLES["trans"] + max(valu - fma - trans, 0.0) * ISSUE_CYCLES["other_valu"]
+                + salu * ISSUE_CYCLES["salu"]) / per
+    kernel_ms = prof.get("kernel_avg_ms", measured_ms)
+    return {"bound": "valu_issue", "kernel": "render_fb_wave_kernel", "valu_instructions_per_launch": valu, "salu_instructions_per_launch": salu,
+            "transcendental_per_launch": trans, "fma_mul_add_per_launch": fma, "floor_ms_lower": 1e3 * lower, "floor_ms_by_class": 1e3 * by_class,
+            "kernel_ms_rocprof": kernel_ms, "frac_lower": 1e3 * lower / kernel_ms, "frac_by_class": 1e3 * by_class / kernel_ms,
+            "cycles_per_valu_instruction_per_simd": kernel_ms * 1e-3 * per / valu, "class_cycles": ISSUE_CYCLES,
+            "source": f"profiles/{PROFILE_ROUND}/sq_issue_{config}.json"}
 
 
 def cpu_baseline(batch, H, W, min_seconds=10.0, max_views=8):
@@ -338,7 +377,7 @@ def main():
         from unipre3d_amd.rasterizer import _Plan
         with torch.no_grad():   # R of the Gaussians the timed steps actually rendered (from head_out, not batch.raw)
             g_used = synthetic.gaussians_from_batch(synthetic.SyntheticBatch(**dict(batch.__dict__, raw=head_out.detach().permute(0, 2, 1))))
-        R_mean = _read_num_rendered(g_used, batch, H, W, t)
+        R_mean, walk_stats = _read_num_rendered(g_used, batch, H, W, t)
         NV = B * V
         kernels = {}
         for k, (ms, cnt) in prof.items():
@@ -361,19 +400,31 @@ def main():
             "config": {"workload": f"{a.config}: render-loss hot path (activations + render fwd + loss + render bwd), {level}-level, P={P} Gaussians/object, {H}x{W}, "
                                    f"B={B}/GPU x V={V} views = {NV} renders/GPU/step" + (" (compact splats)" if a.compact else ""),
                        "global_batch": B * world, "views_per_step": NV * world, "parallelism": f"dp{world}",
-                       "loss": loss_kind, "num_rendered_per_view": R_mean,
+                       "loss": loss_kind, "num_rendered_per_view": R_mean, "list_consumption": walk_stats,
                        "path": "unfused (torch activations/loss)" if a.unfused else "fused head-activation + render + loss (HIP)"},
             "render_loss_step_ms": {"rasterizer_kernels_total": fb_ms, "kernels": kernels},
             "final_loss": float(loss),
         }
+        default_path = not (a.unfused or a.compact or a.two_pass)
         if dom:
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS,
-                               "traffic": pmc_traffic(dom, a.config, not (a.unfused or a.compact or a.two_pass)),
+                               "traffic": pmc_traffic(dom, a.config, default_path),
                                "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_GB_per_launch"] * 1e9,
                                "scope": ("one HIP-event scope per launch of the tile kernel TOGETHER WITH the bwd_reduce kernel that finishes its "
                                          "gradient accumulation (rocprofv3 lists the two separately: their averages add up to this duration)")
                                         if dom in ("render_fb", "render_bwd") else "one HIP-event scope per launch of the kernel"}
+            tr = out["roofline"]["traffic"]
+            if tr:
+                # what this design really moves (it never materialises the per-instance lists the algorithmic figure prices):
+                out["roofline_hbm_actual"] = {"bound": "hbm", "achieved": tr / 1e9 / (kernels[dom]["avg_ms"] / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": tr / 1e9 / (kernels[dom]["avg_ms"] / 1e3) / HBM_PEAK_GBS, "bytes_per_launch": tr,
+                                              "ratio_to_algorithmic": tr / (kernels[dom]["algorithmic_GB_per_launch"] * 1e9),
+                                              "note": "PMC-measured HBM bytes of the same scope over the same live duration: the kernels are not "
+                                                      "HBM-bound, see roofline_issue"}
+            ri = issue_roofline(a.config, default_path, kernels[dom]["avg_ms"])
+            if ri:
+                out["roofline_issue"] = ri
             out["roofline_rasterizer_fwd_bwd"] = {"achieved": (fwd_bytes + bwd_bytes) / 1e9 / (fb_ms / 1e3), "peak": HBM_PEAK_GBS,
                                                   "unit": "GB/s", "frac": (fwd_bytes + bwd_bytes) / 1e9 / (fb_ms / 1e3) / HBM_PEAK_GBS,
                                                   "note": "reference-algorithm bytes fwd (168P+76R+8T+24HW) + bwd (308P+76R+24HW) per view "
@@ -462,8 +513,8 @@ def main():
         dp.shutdown()
 
 
-def _read_num_rendered(g, batch, H, W, t) -> float:
-    """Mean over views of R = sum over Gaussians of tiles touched, read from the kernel's own counter."""
+def _read_num_rendered(g, batch, H, W, t):
+    """(mean over views of R = sum over Gaussians of tiles touched, read from the kernel's own counter; list-consumption statistics)."""
     import ctypes
     from unipre3d_amd import head
     from unipre3d_amd.rasterizer import _Plan
@@ -488,7 +539,17 @@ def _read_num_rendered(g, batch, H, W, t) -> float:
     torch.cuda.synchronize()
     off = plan.sizes.num_rendered_offset
     nr = geom[off:off + 4 * NV].view(torch.int32).to(torch.float64)
-    return float(nr.mean().item())
+    # how deep the tiles really walk the view's sorted list (what this design's cost follows, SURVEY 8d "list length consumed"):
+    # tile_last = last sorted position that contributed to any pixel of the tile (image scratch: final_T | n_contrib | tile_last)
+    al = lambda n: ((n + 255) // 256) * 256
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    tl = (image[2 * al(4 * NV * H * W):][: 4 * NV * T].view(torch.int32) & 0x7fffffff).to(torch.float64)
+    lim = image[al(4 * NV * H * W):][: 4 * NV * H * W].view(torch.int32).to(torch.int64) & 0xffffffff
+    sat = (lim != 0xffffffff)
+    stats = {"sorted_positions_walked_per_tile_mean": float(tl.mean().item()), "sorted_positions_walked_per_tile_max": float(tl.max().item()),
+             "pixels_saturated_fraction": float(sat.double().mean().item()),
+             "saturation_position_mean": float(lim[sat].double().mean().item()) if bool(sat.any()) else None}
+    return float(nr.mean().item()), stats
 
 
 if __name__ == "__main__":
