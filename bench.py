@@ -99,11 +99,14 @@ def issue_roofline(config: str, default_path: bool, measured_ms: float):
     lower = ((valu - trans) * ISSUE_CYCLES["fma_class"] + trans * ISSUE_CYCLES["trans"] + salu * ISSUE_CYCLES["salu"]) / per
     by_class = (fma * ISSUE_CYCLES["fma_class"] + trans * ISSUE_CYCLES["trans"] + max(valu - fma - trans, 0.0) * ISSUE_CYCLES["other_valu"]
                 + salu * ISSUE_CYCLES["salu"]) / per
-    kernel_ms = prof.get("kernel_avg_ms", measured_ms)
+    kernel_ms = prof.get("kernel_avg_ms") or measured_ms
+    # shader cycles of the launch as the counters saw them (GRBM_GUI_ACTIVE sums the 8 XCDs); falls back to duration x nominal clock
+    cycles = c["GRBM_GUI_ACTIVE"] / 8.0 if c.get("GRBM_GUI_ACTIVE") else kernel_ms * 1e-3 * SHADER_CLOCK_HZ
+    lower, by_class = lower * SHADER_CLOCK_HZ / cycles * kernel_ms * 1e-3, by_class * SHADER_CLOCK_HZ / cycles * kernel_ms * 1e-3   # floors in measured cycles -> seconds
     return {"bound": "valu_issue", "kernel": "render_fb_wave_kernel", "valu_instructions_per_launch": valu, "salu_instructions_per_launch": salu,
             "transcendental_per_launch": trans, "fma_mul_add_per_launch": fma, "floor_ms_lower": 1e3 * lower, "floor_ms_by_class": 1e3 * by_class,
             "kernel_ms_rocprof": kernel_ms, "frac_lower": 1e3 * lower / kernel_ms, "frac_by_class": 1e3 * by_class / kernel_ms,
-            "cycles_per_valu_instruction_per_simd": kernel_ms * 1e-3 * per / valu, "class_cycles": ISSUE_CYCLES,
+            "cycles_per_valu_instruction_per_simd": cycles * N_SIMD / valu, "shader_cycles_per_launch": cycles, "class_cycles": ISSUE_CYCLES,
             "source": f"profiles/{PROFILE_ROUND}/sq_issue_{config}.json"}
 
 
