@@ -408,11 +408,12 @@ def main():
             "render_loss_step_ms": {"rasterizer_kernels_total": fb_ms, "kernels": kernels},
             "final_loss": float(loss),
         }
-        default_path = not (a.unfused or a.compact or a.two_pass)
+        default_path = not (a.unfused or a.two_pass)
+        prof_cfg = a.config + ("_compact" if a.compact else "")
         if dom:
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS,
-                               "traffic": pmc_traffic(dom, a.config, default_path),
+                               "traffic": pmc_traffic(dom, prof_cfg, default_path),
                                "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_GB_per_launch"] * 1e9,
                                "scope": ("one HIP-event scope per launch of the tile kernel TOGETHER WITH the bwd_reduce kernel that finishes its "
                                          "gradient accumulation (rocprofv3 lists the two separately: their averages add up to this duration)")
@@ -425,7 +426,7 @@ def main():
                                               "ratio_to_algorithmic": tr / (kernels[dom]["algorithmic_GB_per_launch"] * 1e9),
                                               "note": "PMC-measured HBM bytes of the same scope over the same live duration: the kernels are not "
                                                       "HBM-bound, see roofline_issue"}
-            ri = issue_roofline(a.config, default_path, kernels[dom]["avg_ms"])
+            ri = issue_roofline(prof_cfg, default_path, kernels[dom]["avg_ms"])
             if ri:
                 out["roofline_issue"] = ri
             out["roofline_rasterizer_fwd_bwd"] = {"achieved": (fwd_bytes + bwd_bytes) / 1e9 / (fb_ms / 1e3), "peak": HBM_PEAK_GBS,

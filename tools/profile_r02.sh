@@ -5,15 +5,17 @@
 #   gpurun_out/prof_r02/pmc_traffic_<cfg>.json         separate --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled: gfx950 calibration)
 #   gpurun_out/prof_r02/sq_issue_<cfg>.json            (with `sq`) SQ instruction counters of the tile kernel, two --pmc passes
 # Copy what is to be judged into profiles/r02/.
-CFG=${1:-C2}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r02; mkdir -p $O
+# A third argument is passed on to bench.py (e.g. --compact) and names the files <cfg>_<tag>: tools/profile_r02.sh C2 sq --compact
+CFGNAME=${1:-C2}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r02; mkdir -p $O
+EXTRA=$3; CFG=$CFGNAME; if [ -n "$EXTRA" ]; then CFG=${CFGNAME}_${EXTRA#--}; fi
 cd /tmp && export TMPDIR=/tmp
-ARGS="--config $CFG --steps 50 --warmup 10"
+ARGS="--config $CFGNAME $EXTRA --steps 50 --warmup 10"
 if [ "$CFG" = "C2" ]; then python $R/bench.py $ARGS > $O/bench_line_$CFG.json 2> $O/bench_$CFG.err
 else python $R/bench.py $ARGS --hot-only --cpu-seconds 10 > $O/bench_line_$CFG.json 2> $O/bench_$CFG.err; fi
 rm -rf /tmp/kt_$CFG; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$CFG -- python $R/bench.py $ARGS --no-cpu-baseline --hot-only > $O/kt_$CFG.log 2>&1
 cp $(find /tmp/kt_$CFG -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bench_$CFG.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --hot-only > $O/pmc_${c}_$CFG.log 2>&1
+  rm -rf /tmp/pmc_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --config $CFGNAME $EXTRA --steps 10 --warmup 3 --no-cpu-baseline --hot-only > $O/pmc_${c}_$CFG.log 2>&1
   cp $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) /tmp/cc_$c.csv
 done
 python - $CFG <<'PY' > $O/pmc_traffic_$CFG.json
@@ -43,7 +45,7 @@ if [ "$2" = "sq" ]; then
   i=0
   for P in "$P1" "$P2"; do
     i=$((i+1)); rm -rf /tmp/sq_$i
-    rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/sq_$i -- python $R/bench.py --config $CFG --steps 6 --warmup 2 --no-cpu-baseline --hot-only > $O/sq_${i}_$CFG.log 2>&1
+    rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/sq_$i -- python $R/bench.py --config $CFGNAME $EXTRA --steps 6 --warmup 2 --no-cpu-baseline --hot-only > $O/sq_${i}_$CFG.log 2>&1
     cp $(find /tmp/sq_$i -name "*counter_collection.csv" | head -1) /tmp/sq_$i.csv
   done
   python - $CFG $O <<'PY' > $O/sq_issue_$CFG.json
