@@ -43,3 +43,20 @@ def test_bench_self_launches_two_ranks():
     assert e2e["collective_backend"] == "gloo" and e2e["gradient_bytes_all_reduced_per_step"] == 4 * 29_464_215
     assert e2e["n1_same_region"]["ms_per_step"] > 0 and e2e["value"] > 0
     assert "error" not in out["train_step_with_head"], out["train_step_with_head"]
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's multi-GPU form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- ranks come from the environment.  Two ranks share cuda:0 over gloo here (RCCL needs
+    one device per rank)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C1", "--steps", "4", "--warmup", "1",
+           "--no-cpu-baseline", "--no-e2e"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, U3D_BENCH_BACKEND="gloo"))
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and "error" not in out["train_step_with_head"]

@@ -1,5 +1,6 @@
 """Fused render-loss step (SURVEY.md N2 + N3): from the Gaussian head's Linear output to the scalar loss in one
-launch sequence of the HIP library (`u3d_render_loss_forward/_backward`).
+launch sequence of the HIP library -- `u3d_render_loss_step` (training: forward AND backward in one sequence, behind the C++
+autograd function of csrc/u3d_torch.cpp) or `u3d_render_loss_forward/_backward` (images kept / differentiable; ctypes, below).
 
 Replaces, per training step: the activation/reshape chain of model/gaussian_predictor.py:279-328, the SH concat and
 operator call of gaussian_renderer/__init__.py:78-97, the per-object/per-view loop and torch.stack of

@@ -49,10 +49,6 @@ def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
     return t.contiguous()
 
 
-def _none_if_empty(t):
-    return None if (t is None or t.numel() == 0) else t
-
-
 class _Plan:
     """Descriptor + scratch sizes for one call shape (cached).  Ragged batches (total_P > 0) share the sizes of their
     (n_items, views, largest set, total) shape; the device pointer to the prefix sums is set per call (`with_offsets`)."""
