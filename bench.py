@@ -337,6 +337,8 @@ def main():
             hot_step()
         torch.cuda.synchronize()
     elapsed, prof, loss = timed(hot_step, True, prof_stride=4)   # every 4th launch of the dominant kernel carries events
+    # run-to-run spread of the same K-step region (not `value`: five further repeats without the event scopes)
+    reps = sorted(1e3 * timed(hot_step, False, warmup=0)[0] / a.steps for _ in range(5))
     _, prof_small, _ = timed(hot_step, True, steps=10, warmup=2, kinds=("preprocess_fwd", "depth_sort", "preprocess_bwd"))
     prof = {k: (prof[k] if prof[k][1] else prof_small[k]) for k in prof}
 
@@ -407,6 +409,8 @@ def main():
                        "path": "unfused (torch activations/loss)" if a.unfused else "fused head-activation + render + loss (HIP)"},
             "render_loss_step_ms": {"rasterizer_kernels_total": fb_ms, "kernels": kernels},
             "final_loss": float(loss),
+            "repeatability": {"what": f"five further repeats of the same {a.steps}-step timed region, ms per step", "min": reps[0], "median": reps[2],
+                              "max": reps[4], "timed_region_ms": 1e3 * elapsed},
         }
         default_path = not (a.unfused or a.two_pass)
         prof_cfg = a.config + ("_compact" if a.compact else "")

@@ -177,3 +177,25 @@ def test_scratch_query_rejects_index_overflow(lib):
     assert lib.u3d_scratch_query(ctypes.byref(pairs), ctypes.byref(sizes)) == 2
     fine = _lib.RasterDesc(32, 4, 128, 256, 256, 0.5, 0.5, 1.0, 1, 4, 2)
     assert lib.u3d_scratch_query(ctypes.byref(fine), ctypes.byref(sizes)) == 0
+
+
+def test_ragged_host_helpers():
+    """pack_ragged / split_ragged_radii / the fused route's shape checks (host logic only)."""
+    import torch
+    from unipre3d_amd import fused
+    from unipre3d_amd.rasterizer import pack_ragged, split_ragged_radii
+    parts = [torch.arange(6.).reshape(2, 3), torch.zeros(0, 3), torch.ones(3, 3)]
+    packed, off, sizes = pack_ragged(parts)
+    assert packed.shape == (5, 3) and off.tolist() == [0, 2, 2, 5] and off.dtype == torch.int32 and sizes == [2, 0, 3]
+    V = 2
+    radii = torch.arange(V * 5)
+    per = split_ragged_radii(radii, sizes, V)
+    assert [tuple(p.shape) for p in per] == [(2, 2), (2, 0), (2, 3)]
+    assert per[0].tolist() == [[0, 1], [2, 3]] and per[2].tolist() == [[4, 5, 6], [7, 8, 9]]      # set i, view v at V*off_i + v*P_i
+    h3, h2 = torch.zeros(2, 7, 23), torch.zeros(9, 23)
+    assert fused._batch_shape(h3, None, 0) == (2, 7, 23, 0)
+    assert fused._batch_shape(h2, torch.tensor([0, 4, 9], dtype=torch.int32), 5) == (2, 5, 23, 9)
+    for bad in ((h2, None, 0), (h3, torch.tensor([0, 1], dtype=torch.int32), 1), (h2, torch.tensor([0, 9]), 9),
+                (h2, torch.tensor([0, 9], dtype=torch.int32), 0), (h2, torch.tensor([0, 9], dtype=torch.int32), 10)):
+        with pytest.raises(ValueError):
+            fused._batch_shape(*bad)

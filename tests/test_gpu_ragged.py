@@ -18,21 +18,27 @@ def _sets(sizes, V, H, W, level, seed):
     dev = torch.device("cuda:0")
     out = []
     for k, n in enumerate(sizes):
-        b = synthetic.make_batch(1, n, V, H, W, level=level, seed=seed + k).to(dev)
+        b = synthetic.make_batch(1, max(n, 1), V, H, W, level=level, seed=seed + k).to(dev)     # (cameras / targets; empty sets: see the test)
         out.append(b)
     return out
 
 
-@pytest.mark.parametrize("sizes,level", [((100, 37, 256), "object"), ((300, 2048, 1000), "scene"), ((700, 5000, 1, 4200), "scene")])
+@pytest.mark.parametrize("sizes,level", [((100, 37, 256), "object"), ((300, 2048, 1000), "scene"), ((700, 5000, 1, 4200), "scene"),
+                                         ((64, 0, 200), "scene"), ((0, 5000), "scene")])
 def test_ragged_operator_equals_one_call_per_set(sizes, level):
     """Covers the three sort routes (largest set <= 256: fused into the projection kernel; <= 4096: one-workgroup LDS sort;
-    beyond: bucketed), sets shorter than a workgroup's span, and a one-Gaussian set."""
+    beyond: bucketed), sets shorter than a workgroup's span, a one-Gaussian set and EMPTY sets (background-only views)."""
     from unipre3d_amd import head, synthetic
     from unipre3d_amd.rasterizer import pack_ragged, rasterize_gaussians_batched, split_ragged_radii
     V, H, W = 2, 64, 80
     bs = _sets(sizes, V, H, W, level, 40)
     t = math.tan(bs[0].fov_deg * math.pi / 360)
-    gs = [{k: v[0].detach().clone().requires_grad_(True) for k, v in synthetic.gaussians_from_batch(b).items()} for b in bs]
+    def gaussians(b, n):
+        if n == 0:      # (the reference's scene branch cannot produce an empty set; the operator must still accept one)
+            sh = {"xyz": (0, 3), "opacity": (0, 1), "scaling": (0, 3), "rotation": (0, 4), "features_dc": (0, 1, 3), "features_rest": (0, 3, 3)}
+            return {k: torch.zeros(v, device="cuda", requires_grad=True) for k, v in sh.items()}
+        return {k: v[0].detach().clone().requires_grad_(True) for k, v in synthetic.gaussians_from_batch(b).items()}
+    gs = [gaussians(b, n) for b, n in zip(bs, sizes)]
     cot = torch.randn(len(sizes), V, 3, H, W, generator=torch.Generator().manual_seed(2)).cuda()
     # one call per set
     ref = []
@@ -43,7 +49,8 @@ def test_ragged_operator_equals_one_call_per_set(sizes, level):
         col, radii, inv = rasterize_gaussians_batched(g["xyz"][None], g["opacity"][None], b.world_view, b.full_proj, b.camera_center, b.bg, H, W, t, t,
                                                       shs=shs[None], scales=g["scaling"][None], rotations=g["rotation"][None], sh_degree=1, means2D=m2d)
         (col * cot[i]).sum().backward()
-        ref.append((col.detach(), radii, inv.detach(), {k: g[k].grad.clone() for k in KEYS}, shs.grad.clone(), m2d.grad.clone()))
+        grad = lambda t: t.grad.clone() if t.grad is not None else torch.zeros_like(t)
+        ref.append((col.detach(), radii, inv.detach(), {k: grad(g[k]) for k in KEYS}, grad(shs), grad(m2d)))
         for k in KEYS:
             g[k].grad = None
     # the same sets packed into ONE launch sequence
@@ -65,9 +72,13 @@ def test_ragged_operator_equals_one_call_per_set(sizes, level):
         assert torch.equal(r_list[i], ref[i][1][0]), i
         for k in KEYS:       # (the cross-slice f64 atomics of the gradient reduction are order-insensitive, not bit-identical)
             a, b_ = gs[i][k].grad, ref[i][3][k]
+            if n == 0:
+                assert a is None or a.numel() == 0
+                continue
             assert rel_l2(a.cpu().numpy(), b_.cpu().numpy()) < 1e-6 if b_.abs().sum() > 0 else not a.any(), (i, k)
-        assert rel_l2(shs_p.grad[o:o + n].cpu().numpy(), ref[i][4].cpu().numpy()) < 1e-6
-        assert rel_l2(m_list[i].cpu().numpy(), ref[i][5].cpu().numpy()) < 1e-6
+        if n:
+            assert rel_l2(shs_p.grad[o:o + n].cpu().numpy(), ref[i][4].cpu().numpy()) < 1e-6
+            assert rel_l2(m_list[i].cpu().numpy(), ref[i][5].cpu().numpy()) < 1e-6
         o += n
 
 
