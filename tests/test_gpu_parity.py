@@ -332,3 +332,23 @@ def test_g8_analytic_known_answers(golden):
 
     rep = run_g8(golden("g8_analytic.npz"), render)
     print("g8 analytic:", {k: f"{v:.1e}" for k, v in rep.items()})
+
+
+def test_operator_refuses_inconsistent_shapes():
+    """The C-ABI trusts its sizes; the binding refuses tensors whose shapes do not add up (upstream raises on means3D not (P, 3))."""
+    from unipre3d_amd.rasterizer import GaussianRasterizer, rasterize_gaussians_batched
+    dev = torch.device("cuda:0")
+    sc = scene(16, 20, 36, seed=2)
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()}
+    rast = GaussianRasterizer(_settings(sc, t))
+    good = dict(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                rotations=t["rotations"])
+    rast(**good)
+    for key, bad in (("means3D", t["means3D"].t().contiguous()), ("opacities", t["opacities"][:-1]), ("scales", t["scales"][:, :2].contiguous()),
+                     ("rotations", t["rotations"][:8]), ("shs", t["shs"][:, :, :2].contiguous()), ("means2D", torch.zeros(3, 3, device=dev))):
+        with pytest.raises(RuntimeError):
+            rast(**dict(good, **{key: bad}))
+    with pytest.raises(RuntimeError):
+        rasterize_gaussians_batched(t["means3D"][None], t["opacities"][None], t["viewmatrix"][None, None].expand(1, 2, 4, 4)[:, :1], t["projmatrix"][None, None],
+                                    t["campos"][None, None, :2], t["bg"], 20, 36, 0.5, 0.5, shs=t["shs"][None], scales=t["scales"][None],
+                                    rotations=t["rotations"][None], sh_degree=1)

@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 from unipre3d_amd import synthetic, dp
 from unipre3d_amd.fused import render_loss_fused, backward_unit
 dev = torch.device("cuda")

@@ -124,6 +124,22 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                   "item_offsets must be a contiguous int32 tensor of n_items + 1 prefix sums on the Gaussians' device");
       TORCH_CHECK(!single && total_P > 0 && max_P > 0 && max_P <= total_P, "ragged batch: bad total / largest set size");
     }
+    {
+      // the C-ABI trusts its sizes: refuse tensors whose shapes do not add up (upstream's extension raises on means3D not (P, 3))
+      const int64_t G = ragged ? total_P : (single ? P : n_items * P);     // Gaussians in the call
+      const int64_t NVc = n_items * vpi;
+      TORCH_CHECK(means3D.size(-1) == 3 && means3D.numel() == G * 3, "means3D must be (", single ? "" : "sets, ", "P, 3)");
+      TORCH_CHECK(opac.numel() == G, "opacities must hold one value per Gaussian");
+      TORCH_CHECK(!shs.defined() || (shs.size(-1) == 3 && shs.numel() == G * M * 3), "shs must be (..., P, M, 3)");
+      TORCH_CHECK(!colors.defined() || colors.numel() == G * 3, "colors_precomp must be (..., P, 3)");
+      TORCH_CHECK(!scales.defined() || scales.numel() == G * 3, "scales must be (..., P, 3)");
+      TORCH_CHECK(!rots.defined() || rots.numel() == G * 4, "rotations must be (..., P, 4)");
+      TORCH_CHECK(!cov.defined() || cov.numel() == G * 6, "cov3D_precomp must be (..., P, 6)");
+      TORCH_CHECK(view.numel() == NVc * 16 && proj.numel() == NVc * 16 && campos.numel() == NVc * 3 && bg.numel() == 3,
+                  "cameras must be (views, 4, 4), (views, 4, 4), (views, 3) and bg (3,)");
+      if (means2D_.has_value() && means2D_->defined())
+        TORCH_CHECK(means2D_->numel() == (ragged ? vpi * total_P : (single ? P : NVc * P)) * 3, "means2D must be (views, P, 3)");
+    }
     u3d_raster_desc d{};
     d.n_items = (int32_t)n_items; d.views_per_item = (int32_t)vpi; d.P = (int32_t)P;
     d.image_height = (int32_t)H; d.image_width = (int32_t)W;
@@ -254,6 +270,12 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
     TORCH_CHECK(B > 0 && NV % B == 0, NV, " cameras for ", B, " Gaussian sets: every set needs the same number of views");
     TORCH_CHECK(C == 11 + 3 * K, "head output has ", C, " channels, expected ", 11 + 3 * K, " for SH degree ", sh_degree);
     const int64_t V = NV / B;
+    {
+      const int64_t G = ragged ? total_P : B * P;
+      TORCH_CHECK(center.numel() == G * 3, "center must be (..., P, 3)");
+      TORCH_CHECK(view.numel() == NV * 16 && proj.numel() == NV * 16 && campos.numel() == NV * 3 && bg.numel() == 3 && gt.numel() == NV * 3 * H * W,
+                  "cameras must be (views, 16), (views, 16), (views, 3), bg (3,) and gt (views, 3, H, W)");
+    }
     u3d_raster_desc d{};
     d.n_items = (int32_t)B; d.views_per_item = (int32_t)V; d.P = (int32_t)P; d.image_height = (int32_t)H; d.image_width = (int32_t)W;
     d.tanfovx = d.tanfovy = (float)tanfov; d.scale_modifier = (float)scale_modifier; d.sh_degree = (int32_t)sh_degree;
