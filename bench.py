@@ -339,6 +339,13 @@ def main():
     elapsed, prof, loss = timed(hot_step, True, prof_stride=4)   # every 4th launch of the dominant kernel carries events
     # run-to-run spread of the same K-step region (not `value`: five further repeats without the event scopes)
     reps = sorted(1e3 * timed(hot_step, False, warmup=0)[0] / a.steps for _ in range(5))
+    # host cost of issuing one step (the launches of 16 steps against an empty queue, before any synchronisation)
+    torch.cuda.synchronize()
+    t_h = time.perf_counter()
+    for _ in range(16):
+        hot_step()
+    host_us = 1e6 * (time.perf_counter() - t_h) / 16
+    torch.cuda.synchronize()
     _, prof_small, _ = timed(hot_step, True, steps=10, warmup=2, kinds=("preprocess_fwd", "depth_sort", "preprocess_bwd"))
     prof = {k: (prof[k] if prof[k][1] else prof_small[k]) for k in prof}
 
@@ -411,6 +418,7 @@ def main():
             "final_loss": float(loss),
             "repeatability": {"what": f"five further repeats of the same {a.steps}-step timed region, ms per step", "min": reps[0], "median": reps[2],
                               "max": reps[4], "timed_region_ms": 1e3 * elapsed},
+            "hot_step_host_issue_us": host_us,
         }
         default_path = not (a.unfused or a.two_pass)
         prof_cfg = a.config + ("_compact" if a.compact else "")

@@ -10,8 +10,10 @@ and the sharding arithmetic of train_network.py:55-71.  Design differences (MI35
     exchange and RCCL initialisation costs seconds.
   * the render path needs no collective: renders are independent per (object, view).  The single exchange per step
     is DDP's bucketed gradient all-reduce of the PyTorch modules feeding the rasterizer; rasterizer gradients are
-    never communicated.  Bucket size defaults to one 128 MiB bucket-cap for the 117.9 MB transformer config (xGMI is
-    point-to-point: 7 links x ~153 GB/s, so few large ring collectives beat many 25 MiB ones); gradient_as_bucket_view
+    never communicated.  Bucket cap defaults to 32 MiB: four buckets for the 117.9 MB transformer config, so the all-reduce of the
+    late layers' gradients overlaps the backward of the early ones (a single 128 MiB bucket could only start when the whole backward
+    is done), while each ring collective is still large enough to run at link bandwidth (xGMI is point-to-point, 7 links x ~153 GB/s:
+    message size, not message count, is what a ring needs -- PyTorch's 25 MiB default is in the same range); gradient_as_bucket_view
     avoids a copy per step.
   * the object-level reference path does not shard its batch across ranks (train_network.py:114-128 builds loaders
     with the global batch and no sampler); `shard_range` shards both levels.
@@ -202,7 +204,7 @@ def launch_script(script: str, argv, nproc: int, backend: Optional[str] = None, 
 
 
 # ---- model wrap ----------------------------------------------------------------------------
-def create_ddp_model(model: nn.Module, *, sync_bn: bool = True, bucket_cap_mb: int = 128, **kwargs) -> nn.Module:
+def create_ddp_model(model: nn.Module, *, sync_bn: bool = True, bucket_cap_mb: int = 32, **kwargs) -> nn.Module:
     """SyncBN conversion + DistributedDataParallel as ModelManager.setup_distributed does
     (train_network.py:180-186 -> pointcept/engines/defaults.py:22-43; the reference's kwargs broadcast_buffers=False and
     find_unused_parameters=True are the defaults here too: its predictor has branches that do not run in every step, and DDP
