@@ -1,12 +1,26 @@
 """RCCL itself (R9): needs at least two MI355X in the box -- skipped on the 1-GPU test boxes, runs wherever the suite meets a
 multi-GPU node.  DDP-averaged gradients of the head + render-loss step over RCCL must equal the single-process gradients on the
 concatenated batch (the gloo version of this check runs on CPU in tests/test_dp.py)."""
+import json
 import os
+import subprocess
+import sys
 
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+def test_rccl_code_paths_on_one_gpu():
+    """World of one over backend "nccl": the collective library comes up and every RCCL branch of dp.py executes on a single
+    MI355X (communicator, device barrier, DDP buckets + SyncBN around the fused step); only the inter-GPU transport is left to a
+    multi-GPU node.  Own process: the process group must not leak into the other tests."""
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_world1.py")
+    res = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["ok"] and out["backend"] == "nccl"
 
 
 def _worker(out_dir):

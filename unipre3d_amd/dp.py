@@ -57,8 +57,8 @@ def is_main_process() -> bool:
 
 
 def synchronize() -> None:
-    """Barrier among all ranks (no-op for a world of one)."""
-    if get_world_size() == 1:
+    """Barrier among all ranks (no-op without a process group)."""
+    if not (dist.is_available() and dist.is_initialized()):
         return
     if dist.get_backend() == dist.Backend.NCCL:
         dist.barrier(device_ids=[torch.cuda.current_device()])
@@ -69,14 +69,14 @@ def synchronize() -> None:
 def host_barrier() -> None:
     """Barrier over the gloo control group (host side): rank rendezvous that does not touch RCCL -- timing brackets and the
     launcher use it so that a broken collective library cannot take the collective-free render path down with it."""
-    if get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return
     dist.barrier(group=_CTL) if _CTL is not None else synchronize()
 
 
 def host_all_reduce_max(value: float) -> float:
     """MAX over ranks of a host scalar (the 'max over ranks' of a timed region) through the gloo control group."""
-    if get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(value)
     if _CTL is None:
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == dist.Backend.NCCL else torch.device("cpu")
@@ -90,15 +90,18 @@ def host_all_reduce_max(value: float) -> float:
 
 def all_reduce_mean(x: torch.Tensor) -> torch.Tensor:
     """SUM then divide by world: the validation-PSNR reduction of train_network.py:253-256."""
-    if get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(x, op=dist.ReduceOp.SUM)
         x = x / get_world_size()
     return x
 
 
 # ---- process group -------------------------------------------------------------------------
-def init_from_env(backend: Optional[str] = None, timeout: timedelta = DEFAULT_TIMEOUT) -> Tuple[int, int, int]:
-    """Join the job described by the torch.distributed.run environment.  Returns (rank, local_rank, world)."""
+def init_from_env(backend: Optional[str] = None, timeout: timedelta = DEFAULT_TIMEOUT, force_group: bool = False) -> Tuple[int, int, int]:
+    """Join the job described by the torch.distributed.run environment.  Returns (rank, local_rank, world).
+    force_group: create the process group even for a world of one (the reference always does, launch.py:89-97).  With backend
+    "nccl" on one GPU this runs every RCCL code path of this module -- communicator, device barrier, DDP buckets, SyncBN -- except
+    the inter-GPU transport (tests/test_gpu_rccl.py); MASTER_ADDR / MASTER_PORT must then be set like for any job."""
     global _LOCAL_RANK, _CTL
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -106,7 +109,7 @@ def init_from_env(backend: Optional[str] = None, timeout: timedelta = DEFAULT_TI
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         torch.cuda.set_device(_LOCAL_RANK % max(torch.cuda.device_count(), 1))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
             raise RuntimeError("WORLD_SIZE > 1 needs MASTER_PORT (torch.distributed.run and dp.launch both set it): there is no "
@@ -204,14 +207,14 @@ def launch_script(script: str, argv, nproc: int, backend: Optional[str] = None, 
 
 
 # ---- model wrap ----------------------------------------------------------------------------
-def create_ddp_model(model: nn.Module, *, sync_bn: bool = True, bucket_cap_mb: int = 32, **kwargs) -> nn.Module:
+def create_ddp_model(model: nn.Module, *, sync_bn: bool = True, bucket_cap_mb: int = 32, force_ddp: bool = False, **kwargs) -> nn.Module:
     """SyncBN conversion + DistributedDataParallel as ModelManager.setup_distributed does
     (train_network.py:180-186 -> pointcept/engines/defaults.py:22-43; the reference's kwargs broadcast_buffers=False and
     find_unused_parameters=True are the defaults here too: its predictor has branches that do not run in every step, and DDP
     hangs on a parameter that never produces a gradient unless it is told to look for them).  Pass
     find_unused_parameters=False for a module known to use every parameter (saves DDP's per-step graph walk)."""
-    if get_world_size() == 1:
-        return model
+    if get_world_size() == 1 and not (force_ddp and dist.is_available() and dist.is_initialized()):
+        return model        # (force_ddp: wrap even a world of one -- exercises the collective library on a single GPU)
     if sync_bn:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
     on_gpu = next(model.parameters()).is_cuda
