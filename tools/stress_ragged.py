@@ -1,0 +1,42 @@
+"""GPU stress of ragged batches: random set sizes (incl. empty and one-Gaussian sets, all three sort routes), both levels, all losses,
+isotropic on/off: the packed fused step (single-pass and two-pass) must equal one fused call per set."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
+from unipre3d_amd import fused, synthetic
+from unipre3d_amd.rasterizer import pack_ragged
+from conftest import rel_l2
+dev = torch.device("cuda")
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+bad, worst, t0 = 0, 0.0, time.time()
+for it in range(N):
+    B = int(rng.integers(1, 5)); V = int(rng.integers(1, 4)); H = int(rng.integers(8, 100)); W = int(rng.integers(8, 100))
+    pool = [1, 2, 40, 64, 65, 200, 256, 257, 900, 3000, 4096, 4097, 6000]
+    sizes = [int(rng.choice(pool)) for _ in range(B)]
+    level = ("object", "scene")[int(rng.integers(0, 2))]; kind = ("focal_l2", "l2")[int(rng.integers(0, 2))]
+    iso = bool(rng.integers(0, 2)) and level == "object"; sp = bool(rng.integers(0, 2))
+    bs = [synthetic.make_batch(1, n, V, H, W, level=level, seed=int(rng.integers(0, 1 << 30))).to(dev) for n in sizes]
+    ref_l, ref_g, ref_i = [], [], []
+    for b in bs:
+        h = b.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+        l, img, _ = fused.render_loss_fused(h, b.center, b.world_view, b.full_proj, b.camera_center, b.gt, b.bg, b.fov_deg, H, W, level=level,
+                                            offset_scale=b.offset_scale, loss_kind=kind, single_pass=sp, isotropic=iso)
+        l.backward(); ref_l.append(l.item()); ref_g.append(h.grad[0].clone()); ref_i.append(img)
+    hp, off, szs = pack_ragged([b.raw[0].t().contiguous() for b in bs]); hp = hp.detach().requires_grad_(True)
+    cat = lambda n: torch.cat([getattr(b, n) for b in bs])
+    l, img, radii = fused.render_loss_fused(hp, torch.cat([b.center[0] for b in bs]), cat("world_view"), cat("full_proj"), cat("camera_center"), cat("gt"),
+                                            bs[0].bg, bs[0].fov_deg, H, W, level=level, offset_scale=bs[0].offset_scale, loss_kind=kind, single_pass=sp,
+                                            isotropic=iso, item_offsets=off, max_P=max(sizes))
+    l.backward(); torch.cuda.synchronize()
+    ok = abs(l.item() - sum(ref_l) / B) <= 2e-6 * max(abs(l.item()), 1e-12) and torch.isfinite(hp.grad).all().item()
+    o = 0
+    for i, n in enumerate(sizes):
+        ok = ok and torch.equal(img[i * V:(i + 1) * V], ref_i[i])
+        a, r = hp.grad[o:o + n] * B, ref_g[i]
+        e = rel_l2(a.cpu().numpy(), r.cpu().numpy()) if r.abs().sum() > 0 else float(a.abs().sum())
+        worst = max(worst, e); ok = ok and e < 5e-5
+        o += n
+    if not ok:
+        bad += 1; print("CASE", it, dict(sizes=sizes, V=V, H=H, W=W, level=level, kind=kind, iso=iso, single_pass=sp))
+print("cases %d bad %d worst gradient rel-L2 %.2e (%.1f s)" % (N, bad, worst, time.time() - t0))
