@@ -43,6 +43,12 @@ def test_bench_self_launches_two_ranks():
     assert e2e["collective_backend"] == "gloo" and e2e["gradient_bytes_all_reduced_per_step"] == 4 * 29_464_215
     assert e2e["n1_same_region"]["ms_per_step"] > 0 and e2e["value"] > 0
     assert "error" not in out["train_step_with_head"], out["train_step_with_head"]
+    # the same launch quoting the step WITH the exchange in it as `value`
+    out2 = _run(["--gpus", "2", "--config", "C1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--value-region", "train"],
+                env={"U3D_BENCH_SHARE_GPU": "1", "U3D_BENCH_EXTRAS_BUDGET_S": "240"})
+    e = out2["train_step_e2e_standin"]
+    assert out2["value"] == e["value"] and out2["ms_per_step"] == e["ms_per_step"] and out2["hot_path"]["value"] > out2["value"]
+    assert out2["config"]["workload"].startswith("END-TO-END")
 
 
 def test_bench_under_torch_distributed_run():
