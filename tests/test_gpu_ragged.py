@@ -162,3 +162,49 @@ def test_isotropic_head_variant(single_pass):
     # and it is a different render from the anisotropic one
     _, img_a, _ = fused.render_loss_fused(h.detach(), b.center, b.world_view, b.full_proj, b.camera_center, b.gt, b.bg, b.fov_deg, 64, 64)
     assert rel_l2(img.cpu().numpy(), img_a.cpu().numpy()) > 1e-2
+
+
+def test_fuzz_ragged_fused_step():
+    """40 seeded draws: 1-4 sets of sizes from {1, 2, 40, 64, 65, 200, 256, 257, 900, 3000, 4096, 4097, 6000} (all three sort routes mixed
+    inside one batch), 1-3 views, images 8..100 px, both levels, two losses, isotropic on / off, single-pass and two-pass: the packed
+    fused step equals one fused call per set (image bit for bit; loss; gradient to the re-rounding of the 1/B seed)."""
+    from unipre3d_amd import fused, synthetic
+    from unipre3d_amd.rasterizer import pack_ragged
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(20260929)
+    pool = [1, 2, 40, 64, 65, 200, 256, 257, 900, 3000, 4096, 4097, 6000]
+    for it in range(40):
+        B, V = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+        H, W = int(rng.integers(8, 100)), int(rng.integers(8, 100))
+        sizes = [int(rng.choice(pool)) for _ in range(B)]
+        level = ("object", "scene")[int(rng.integers(0, 2))]
+        kind = ("focal_l2", "l2")[int(rng.integers(0, 2))]
+        iso = bool(rng.integers(0, 2)) and level == "object"
+        sp = bool(rng.integers(0, 2))
+        bs = [synthetic.make_batch(1, n, V, H, W, level=level, seed=int(rng.integers(0, 1 << 30))).to(dev) for n in sizes]
+        tag = (it, sizes, V, H, W, level, kind, iso, sp)
+        ref_l, ref_g, ref_i = [], [], []
+        for b in bs:
+            h = b.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+            l, img, _ = fused.render_loss_fused(h, b.center, b.world_view, b.full_proj, b.camera_center, b.gt, b.bg, b.fov_deg, H, W, level=level,
+                                                offset_scale=b.offset_scale, loss_kind=kind, single_pass=sp, isotropic=iso)
+            l.backward()
+            ref_l.append(l.item()); ref_g.append(h.grad[0].clone()); ref_i.append(img)
+        hp, off, _ = pack_ragged([b.raw[0].t().contiguous() for b in bs])
+        hp = hp.detach().requires_grad_(True)
+        cat = lambda n: torch.cat([getattr(b, n) for b in bs])
+        l, img, radii = fused.render_loss_fused(hp, torch.cat([b.center[0] for b in bs]), cat("world_view"), cat("full_proj"), cat("camera_center"),
+                                                cat("gt"), bs[0].bg, bs[0].fov_deg, H, W, level=level, offset_scale=bs[0].offset_scale, loss_kind=kind,
+                                                single_pass=sp, isotropic=iso, item_offsets=off, max_P=max(sizes))
+        l.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(hp.grad).all() and abs(l.item() - sum(ref_l) / B) <= 2e-6 * max(abs(l.item()), 1e-12), tag
+        o = 0
+        for i, n in enumerate(sizes):
+            assert torch.equal(img[i * V:(i + 1) * V], ref_i[i]), tag
+            a, r = hp.grad[o:o + n] * B, ref_g[i]
+            if r.abs().sum() > 0:
+                assert rel_l2(a.cpu().numpy(), r.cpu().numpy()) < 1e-4, tag
+            else:
+                assert not a.any(), tag
+            o += n
