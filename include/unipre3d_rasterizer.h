@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define U3D_ABI_VERSION 3
+#define U3D_ABI_VERSION 4
 
 /* flags (fields 11-13 of GaussianRasterizationSettings, gaussian_renderer/__init__.py:56-58) */
 #define U3D_FLAG_PREFILTERED 1   /* accepted, no effect: culled points are dropped either way */
@@ -77,7 +77,9 @@ typedef struct u3d_raster_desc {
      PACKED, [total_P][...] in set order; per-(view, Gaussian) outputs (radii, dL_dmeans2D) are packed
      [views_per_item * total_P] with the pairs of set i, view v at  views_per_item * item_offsets[i] + v * P_i . */
   int32_t total_P;
-  const int32_t* item_offsets; /* DEVICE pointer to n_items + 1 prefix sums (first 0, last total_P); NULL iff total_P == 0 */
+  const int32_t* item_offsets; /* DEVICE pointer to n_items + 1 prefix sums (first 0, last total_P); NULL iff total_P == 0.
+                                  Trusted: checked on the device only under U3D_FLAG_DEBUG (U3D_ERR_INVALID_ARGUMENT); a set that
+                                  claims more than P Gaussians is truncated to P */
 } u3d_raster_desc;
 
 typedef struct u3d_scratch_sizes {
@@ -205,6 +207,27 @@ int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head,
                          const float* head_out, const float* center, const float* viewmatrix, const float* projmatrix,
                          const float* campos, const float* gt, float* out_color, int32_t* radii, float* loss_out,
                          float* d_head_out, void* geom, void* binning, void* fused, void* backward_scratch, void* stream);
+
+/*
+ * The same step in the two halves autograd calls it in (ABI 4) -- so that a plain `loss.backward()` (train_network.py:333) costs
+ * what the one-call form does: the forward half runs everything up to the loss value and the REDUCED screen-space gradient
+ * accumulators (projection [+ depth sort], the single-pass tile kernel, the fixed-order reduce); the backward half runs the chain
+ * rule from those accumulators to d_head_out (projection backward, across-point quaternion term) and multiplies by the device
+ * scalar `dloss` (autograd's grad_output; NULL = 1) as it READS the accumulators -- no separate d_head * g launch.
+ *   geom, binning, fused, backward_scratch, radii: the forward half's, unmodified in between.
+ * On return of the backward half the gradient accumulators are zero again (U3D_FLAG_ACC_CLEAN); a forward half whose backward
+ * never runs leaves them dirty (the caller withdraws its promise).
+ * u3d_render_loss_step == forward half + backward half with dloss = NULL.
+ */
+int u3d_render_loss_step_forward(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss,
+                                 const float* bg, const float* head_out, const float* center, const float* viewmatrix,
+                                 const float* projmatrix, const float* campos, const float* gt, float* out_color,
+                                 int32_t* radii, float* loss_out, void* geom, void* binning, void* fused,
+                                 void* backward_scratch, void* stream);
+int u3d_render_loss_step_backward(const u3d_raster_desc* desc, const u3d_head_desc* head, const float* head_out,
+                                  const float* center, const float* viewmatrix, const float* projmatrix, const float* campos,
+                                  const int32_t* radii, const float* dloss, const void* geom, const void* binning, void* fused,
+                                  void* backward_scratch, float* d_head_out, void* stream);
 
 /* Frustum test only: replaces `_C.mark_visible` (no caller in the reference tree). present[P] = z_view > 0.2 */
 int u3d_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

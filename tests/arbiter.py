@@ -9,8 +9,9 @@ Two levels, both in fp32 (the restatement at the kernels' own precision) and fp6
     render loss of utils/loss_utils.py (pinned by G4), with the oracle as the differentiable renderer.
 
 Parity bar (`assert_parity`): <= 1e-4 relative L2 of the fp64 arbiter (north_star), or -- for ill-conditioned draws, where
-fp32 arithmetic itself cannot do better -- <= k x the fp32 restatement's own measured distance from the fp64 arbiter.
-The measured distances are returned so that tests can print / bound them.
+fp32 arithmetic itself cannot do better -- <= k x the fp32 restatement's own measured distance from the fp64 arbiter, and never
+more than GAP_CEIL x the tolerance in absolute terms.  The measured distances are returned so that tests can print / bound
+them; cases that pass only through the gap branch are collected in `GAP_PASSES` (printed by the tests that use -s).
 """
 from __future__ import annotations
 
@@ -23,6 +24,8 @@ from conftest import rel_l2
 
 TOL = 1e-4          # BASELINE.json north_star: 1e-4 relative L2 on images and gradients
 GAP_K = 2.0         # allowance over the fp32 restatement's own distance from the fp64 arbiter
+GAP_CEIL = 10.0     # ... capped: the relative branch never accepts more than GAP_CEIL x tol
+GAP_PASSES = []     # (what, e64, gap) of every case that passed only through the gap branch
 
 
 def parity_errors(x, o32, o64):
@@ -32,7 +35,7 @@ def parity_errors(x, o32, o64):
 
 def parity_ok(x, o32, o64, tol=TOL, k=GAP_K):
     e64, e32, gap = parity_errors(x, o32, o64)
-    return e64 <= tol or e64 <= k * gap
+    return e64 <= tol or e64 <= min(k * gap, GAP_CEIL * tol)
 
 
 def assert_parity(x, o32, o64, what="", tol=TOL, k=GAP_K):
@@ -42,8 +45,10 @@ def assert_parity(x, o32, o64, what="", tol=TOL, k=GAP_K):
         assert not np.any(x), f"{what}: oracle is all-zero, HIP is not"
         return 0.0, 0.0, 0.0
     e64, e32, gap = parity_errors(x.reshape(o64.shape), o32, o64)
-    assert e64 <= tol or e64 <= k * gap, \
-        f"{what}: |hip-f64| {e64:.2e}, |hip-f32| {e32:.2e}, fp32 restatement's own gap |f32-f64| {gap:.2e} (bar {tol:.0e} or {k:g} x gap)"
+    assert e64 <= tol or e64 <= min(k * gap, GAP_CEIL * tol), \
+        f"{what}: |hip-f64| {e64:.2e}, |hip-f32| {e32:.2e}, fp32 restatement's own gap |f32-f64| {gap:.2e} (bar {tol:.0e} or {k:g} x gap, capped at {GAP_CEIL * tol:.0e})"
+    if e64 > tol:
+        GAP_PASSES.append((what, e64, gap))
     return e64, e32, gap
 
 
@@ -129,14 +134,16 @@ def head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, dtype=np.float64, sh_d
     return np.stack(out), loss
 
 
-def assert_radii(rd, r32, r64, what=""):
-    """radius = ceil(3 sqrt(lambda_max)) is an integer threshold: two fp32 evaluations (and fp32 vs fp64) land on different
-    sides of it for about one Gaussian in 2000 at radii of 10^3..10^4 px (measured at C3: the fp32 restatement itself differs
-    from the fp64 one in 0-2 of 2048 radii per view).  Bar: same visible set, every radius within 1 of the fp64 arbiter's, and
-    no more such off-by-ones than k x the fp32 restatement's own count (+2)."""
-    rd, r32, r64 = np.asarray(rd), np.asarray(r32), np.asarray(r64)
-    assert np.array_equal(rd > 0, r64 > 0) or np.array_equal(rd > 0, r32 > 0), f"{what}: visible sets differ"
-    n_hip, n_32 = int((rd != r64).sum()), int((r32 != r64).sum())
-    assert np.abs(rd.astype(np.int64) - r64).max(initial=0) <= 1, f"{what}: a radius is off by more than one"
-    assert n_hip <= GAP_K * n_32 + 2, f"{what}: {n_hip} radii differ from the fp64 arbiter (fp32 restatement: {n_32})"
-    return n_hip, n_32
+def assert_radii(rd, r32, r64=None, what=""):
+    """radii are the operator's integer output: BIT-EXACT against the fp32 restatement.  `preprocess_fwd` evaluates the
+    cov3D -> J W -> cov2D -> +0.3 -> det -> lambda -> ceil(3 sqrt(lambda)) -> getRect chain in the oracle's operation order with FMA
+    contraction off and IEEE divide / sqrt (oracle/raster_oracle.c:317-363 is built -ffp-contract=off), so even at radii of
+    10^3..10^4 px, where fp32 and fp64 land on different sides of the ceil for one Gaussian in ~2000, HIP and the fp32 oracle agree.
+    Returns (#radii differing from the fp64 arbiter for HIP, same for the fp32 restatement) -- equal by construction."""
+    rd, r32 = np.asarray(rd), np.asarray(r32)
+    bad = np.flatnonzero(rd != r32)
+    assert bad.size == 0, f"{what}: {bad.size} radii differ from the fp32 oracle, first at {bad[:5]}: hip {rd[bad[:5]]} oracle {r32[bad[:5]]}"
+    if r64 is None:
+        return 0, 0
+    r64 = np.asarray(r64)
+    return int((rd != r64).sum()), int((r32 != r64).sum())

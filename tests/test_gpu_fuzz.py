@@ -31,7 +31,7 @@ def test_fuzz_forward_backward_vs_oracle(oracle_mod, P, H, W, level, compact, de
     color, invd, radii, g = _run_gpu(sc, dcol, dinv)
     r32 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc))
     r64 = oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
-    assert np.array_equal(radii, r32.radii) or np.array_equal(radii, r64.radii)
+    assert np.array_equal(radii, r32.radii)      # integer output: bit-exact against the fp32 restatement
     assert near(color, r32.color, r64.color) and near(invd, r32.invdepth, r64.invdepth)
     g32 = oracle_mod.backward(r32, dcol.numpy(), dinv.numpy())
     g64 = oracle_mod.backward(r64, dcol.numpy().astype(np.float64), dinv.numpy().astype(np.float64))

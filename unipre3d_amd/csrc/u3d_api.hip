@@ -114,6 +114,30 @@ U3DLoss make_loss(const u3d_raster_desc& d, const u3d_loss_desc& l, const float*
   return L;
 }
 
+// Ragged batches: the kernels trust `item_offsets` (n_items + 1 prefix sums on the DEVICE).  With U3D_FLAG_DEBUG the layout is
+// checked before anything is launched: first 0, non-decreasing, no set larger than desc.P, last == total_P.  (Without the flag a
+// set that claims more than desc.P Gaussians is truncated to desc.P by u3d_set_span -- its tail is never projected -- instead
+// of indexing the sort's LDS keys out of bounds; the host bindings derive P and the prefix sums from the sets' sizes themselves.)
+__device__ int g_offsets_bad;
+__global__ void validate_offsets_kernel(const int32_t* __restrict__ off, int n_items, int P, int total_P) {
+  int bad = 0;
+  for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
+    const int a = off[i], b = off[i + 1];
+    if (b < a || b - a > P || a < 0 || b > total_P) bad = 1;
+  }
+  if (threadIdx.x == 0 && (off[0] != 0 || off[n_items] != total_P)) bad = 1;
+  if (bad) g_offsets_bad = 1;
+}
+int validate_offsets(const u3d_raster_desc& d, hipStream_t s) {
+  if (d.total_P <= 0 || !(d.flags & U3D_FLAG_DEBUG)) return U3D_OK;
+  int bad = 0;
+  if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_offsets_bad), &bad, sizeof(int), 0, hipMemcpyHostToDevice, s) != hipSuccess) return U3D_ERR_LAUNCH;
+  hipLaunchKernelGGL(validate_offsets_kernel, dim3(1), dim3(256), 0, s, d.item_offsets, d.n_items, d.P, d.total_P);
+  if (hipMemcpyFromSymbolAsync(&bad, HIP_SYMBOL(g_offsets_bad), sizeof(int), 0, hipMemcpyDeviceToHost, s) != hipSuccess) return U3D_ERR_LAUNCH;
+  if (hipStreamSynchronize(s) != hipSuccess) return U3D_ERR_LAUNCH;
+  return bad ? U3D_ERR_INVALID_ARGUMENT : U3D_OK;
+}
+
 int finish(const u3d_raster_desc* d, hipStream_t s) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -180,6 +204,7 @@ int u3d_rasterize_forward(const u3d_raster_desc* desc, const float* bg, const fl
     if (shs && d.sh_coeffs < (d.sh_degree + 1) * (d.sh_degree + 1)) return U3D_ERR_INVALID_ARGUMENT;
   }
   hipStream_t s = (hipStream_t)stream;
+  if ((rc = validate_offsets(d, s)) != U3D_OK) return rc;
   U3DBuffers b{};
   u3d_carve(d, geom, binning, image, &b);
   if (d.flags & U3D_FLAG_STATS) (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
@@ -263,6 +288,7 @@ int u3d_render_loss_forward(const u3d_raster_desc* desc, const u3d_head_desc* he
       !geom || !binning || !image || !fused)
     return U3D_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
+  if ((rc = validate_offsets(d, s)) != U3D_OK) return rc;
   U3DBuffers b{};
   u3d_carve(d, geom, binning, image, &b);
   U3DFused f{};
@@ -332,19 +358,23 @@ int u3d_render_loss_backward(const u3d_raster_desc* desc, const u3d_head_desc* h
   return finish(desc, s);
 }
 
-int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss, const float* bg,
-                         const float* head_out, const float* center, const float* viewmatrix, const float* projmatrix,
-                         const float* campos, const float* gt, float* out_color, int32_t* radii, float* loss_out,
-                         float* d_head_out, void* geom, void* binning, void* fused, void* backward_scratch, void* stream) {
+// Training form of the fused step, in the two halves autograd calls it in (see the header): everything up to the loss and the
+// reduced screen-space gradient accumulators, then the chain rule back to d(head_out), scaled by the device scalar dL/dloss.
+int u3d_render_loss_step_forward(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss,
+                                 const float* bg, const float* head_out, const float* center, const float* viewmatrix,
+                                 const float* projmatrix, const float* campos, const float* gt, float* out_color,
+                                 int32_t* radii, float* loss_out, void* geom, void* binning, void* fused,
+                                 void* backward_scratch, void* stream) {
   int rc = check_fused(desc, head, loss);
   if (rc != U3D_OK) return rc;
   const u3d_raster_desc& d = *desc;
   const int NV = d.n_items * d.views_per_item;
   if (NV == 0 || d.P == 0) return U3D_ERR_INVALID_ARGUMENT;
-  if (!bg || !head_out || !center || !viewmatrix || !projmatrix || !campos || !gt || !radii || !loss_out || !d_head_out ||
-      !geom || !binning || !fused || !backward_scratch)
+  if (!bg || !head_out || !center || !viewmatrix || !projmatrix || !campos || !gt || !radii || !loss_out || !geom || !binning ||
+      !fused || !backward_scratch)
     return U3D_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
+  if ((rc = validate_offsets(d, s)) != U3D_OK) return rc;
   U3DBuffers b{};
   const U3DLayout Lay = u3d_carve(d, geom, binning, nullptr, &b);
   U3DFused f{};
@@ -367,22 +397,55 @@ int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head,
     ProfScope ps(1, s);
     u3d_launch_depth_sort(d, b, radii, s);
   }
-  const int T = ((d.image_width + U3D_TILE - 1) / U3D_TILE) * ((d.image_height + U3D_TILE - 1) / U3D_TILE);
   const U3DLoss L = make_loss(d, *loss, gt, f.partial, nullptr);
   {
     ProfScope ps(5, s);
     u3d_launch_render_fb(d, b, bg, out_color, L, acc, part, loss_out, s);   // + partial reduce + loss reduce
   }
-  (void)T;
+  return finish(desc, s);
+}
+
+int u3d_render_loss_step_backward(const u3d_raster_desc* desc, const u3d_head_desc* head, const float* head_out,
+                                  const float* center, const float* viewmatrix, const float* projmatrix, const float* campos,
+                                  const int32_t* radii, const float* dloss, const void* geom, const void* binning, void* fused,
+                                  void* backward_scratch, float* d_head_out, void* stream) {
+  const u3d_loss_desc any_loss{1, 0.f, 0.f};   // (the loss is not evaluated here; only the head / shape checks apply)
+  int rc = check_fused(desc, head, &any_loss);
+  if (rc != U3D_OK) return rc;
+  const u3d_raster_desc& d = *desc;
+  const int NV = d.n_items * d.views_per_item;
+  if (NV == 0 || d.P == 0) return U3D_ERR_INVALID_ARGUMENT;
+  if (!head_out || !center || !viewmatrix || !projmatrix || !campos || !radii || !geom || !binning || !fused || !backward_scratch ||
+      !d_head_out)
+    return U3D_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  U3DBuffers b{};
+  u3d_carve(d, (void*)geom, (void*)binning, nullptr, &b);
+  U3DFused f{};
+  u3d_carve_fused(d, fused, &f);
+  double* acc = (double*)backward_scratch;
+  const U3DSource src = head_source(d, *head, head_out, center, f.qnorm);
   U3DGradSink sink{};
   sink.means = d_head_out; sink.opac = d_head_out + 3; sink.scales = d_head_out + 4; sink.rots = d_head_out + 7;
   sink.shs = d_head_out + 11; sink.colors = nullptr; sink.cov = nullptr; sink.means2D = nullptr; sink.qdot = f.qdot;
   {
     ProfScope ps(4, s);
-    u3d_launch_preprocess_bwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, sink, s, acc);   // reads, then re-zeroes, the touched accumulators
+    u3d_launch_preprocess_bwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, sink, s, acc, dloss);   // reads, then re-zeroes, the touched accumulators
   }
   if (head->mode == 1) u3d_launch_quat_fixup(d, head_out + 7, head->channels, f.qnorm, f.qdot, d_head_out + 7, s);
   return finish(desc, s);
+}
+
+int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss, const float* bg,
+                         const float* head_out, const float* center, const float* viewmatrix, const float* projmatrix,
+                         const float* campos, const float* gt, float* out_color, int32_t* radii, float* loss_out,
+                         float* d_head_out, void* geom, void* binning, void* fused, void* backward_scratch, void* stream) {
+  if (!d_head_out) return U3D_ERR_INVALID_ARGUMENT;
+  const int rc = u3d_render_loss_step_forward(desc, head, loss, bg, head_out, center, viewmatrix, projmatrix, campos, gt, out_color, radii,
+                                              loss_out, geom, binning, fused, backward_scratch, stream);
+  if (rc != U3D_OK) return rc;
+  return u3d_render_loss_step_backward(desc, head, head_out, center, viewmatrix, projmatrix, campos, radii, nullptr, geom, binning, fused,
+                                       backward_scratch, d_head_out, stream);
 }
 
 int u3d_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -63,7 +63,9 @@ static inline U3DSpan u3d_span(const u3d_raster_desc& d) { return U3DSpan{d.tota
 static inline size_t u3d_total_P(const u3d_raster_desc& d) { return d.total_P > 0 ? (size_t)d.total_P : (size_t)d.n_items * (size_t)d.P; }
 #ifdef __HIPCC__
 __device__ __forceinline__ void u3d_set_span(const U3DSpan& s, int item, int& Pi, size_t& gbase) {
-  if (s.off) { const int o0 = s.off[item]; Pi = s.off[item + 1] - o0; gbase = (size_t)o0; }
+  // (a set never has more than desc.P Gaussians: a malformed prefix-sum table is truncated here, in every kernel alike, rather
+  // than indexed past the grids and LDS arrays that were sized from desc.P)
+  if (s.off) { const int o0 = s.off[item]; Pi = min(max(s.off[item + 1] - o0, 0), s.P); gbase = (size_t)o0; }
   else { Pi = s.P; gbase = (size_t)item * s.P; }
 }
 __device__ __forceinline__ size_t u3d_pair_base(const U3DSpan& s, int vk, int Pi, size_t gbase) {
@@ -215,7 +217,7 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
                                const float* projmatrix, const float* campos, int32_t* radii, double* acc_zero, hipStream_t s);
 void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, const int32_t* radii, const double* acc,
-                               const U3DGradSink& sink, hipStream_t s, double* acc_reset = nullptr);
+                               const U3DGradSink& sink, hipStream_t s, double* acc_reset = nullptr, const float* gscale = nullptr);
 // true when preprocess_fwd also produces the per-view depth order (P <= 256): skip u3d_launch_depth_sort then
 bool u3d_preprocess_sorts(const u3d_raster_desc& d);
 void u3d_launch_quat_norms(const u3d_raster_desc& d, const float* rots, int s_rots, float* qnorm, float* qdot_zero, hipStream_t s);

@@ -5,6 +5,12 @@
 // backward, looping over that set's views so the per-set gradient needs no atomics.
 #include "u3d_common.h"
 
+// The forward projection is evaluated in the CPU restatement's operation order with FMA contraction OFF (the oracle is built
+// -ffp-contract=off, oracle/Makefile) and IEEE divide / sqrt (hipcc's default for fp32): depth, pixel mean, conic, colour and
+// -- the path's integer outputs -- radius, tile rectangle and num_rendered are then bit-identical to oracle/raster_oracle.c:317-363
+// on the operator route (tests/arbiter.py::assert_radii is np.array_equal).  The backward kernel re-enables contraction below.
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr float SH_C0 = 0.28209479177387814f;
@@ -297,8 +303,8 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
             rgb[0] = src.colors[gi * 3]; rgb[1] = src.colors[gi * 3 + 1]; rgb[2] = src.colors[gi * 3 + 2];
           } else {
             float dir[3] = {p[0] - cam.pos[0], p[1] - cam.pos[1], p[2] - cam.pos[2]};
-            const float inv = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-            dir[0] *= inv; dir[1] *= inv; dir[2] *= inv;
+            const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+            dir[0] /= len; dir[1] /= len; dir[2] /= len;
             sh_to_rgb<D>(shc, dir, rgb, cb);
           }
           radius = r;
@@ -366,7 +372,12 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     U3DSpan span, int vpi, int M, int H, int W, float tanx, float tany, float mod, int flags, size_t NG, U3DSource src,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const double* acc, double* acc_reset,
-    U3DGradSink sink) {
+    U3DGradSink sink, const float* __restrict__ gscale) {
+#pragma clang fp contract(fast)
+  // gscale: device scalar dL/dloss of the fused step (autograd's grad_output) or null (= 1).  Every output of this kernel -- and the
+  // column dot products quat_fixup finishes -- is linear in the accumulators, so scaling them as they are read IS the d_head * g
+  // multiply; a wave-uniform scalar load, no extra launch.
+  const float gs = gscale ? gscale[0] : 1.f;
   // 4 consecutive lanes (a DPP quad) share one Gaussian and split its views: lane&3 = view slot
   __shared__ float s_qdot[4][4];
   const int item = blockIdx.y;
@@ -453,7 +464,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     const bool live = radii[g] > 0 && (cbits & U3D_TOUCHED_BIT) != 0u;   // visible AND handed a gradient by the reduction
     float a[U3D_NACC];
 #pragma unroll
-    for (int k = 0; k < U3D_NACC; ++k) a[k] = live ? (float)acc[(size_t)k * NG + g] : 0.f;
+    for (int k = 0; k < U3D_NACC; ++k) a[k] = live ? (float)acc[(size_t)k * NG + g] * gs : 0.f;
     if (acc_reset && live) {   // single-pass step: hand the accumulators back zeroed (only touched pairs were ever written)
 #pragma unroll
       for (int k = 0; k < U3D_NACC; ++k) acc_reset[(size_t)k * NG + g] = 0.0;
@@ -800,7 +811,7 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 
 void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, const int32_t* radii, const double* acc,
-                               const U3DGradSink& sink, hipStream_t s, double* acc_reset) {
+                               const U3DGradSink& sink, hipStream_t s, double* acc_reset, const float* gscale) {
   const size_t NG = (size_t)d.views_per_item * u3d_total_P(d);
   dim3 grid((d.P + U3D_BLOCK / 4 - 1) / (U3D_BLOCK / 4), d.n_items), block(U3D_BLOCK);
   const int D = src.shs ? d.sh_degree : 0;
@@ -808,7 +819,7 @@ void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 #define LAUNCH(DEG)                                                                                                    \
   hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, u3d_span(d), d.views_per_item, d.sh_coeffs, d.image_height, \
                      d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, flags, NG, src, viewmatrix, projmatrix,    \
-                     campos, radii, b.clamped, acc, acc_reset, sink)
+                     campos, radii, b.clamped, acc, acc_reset, sink, gscale)
   switch (D) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;

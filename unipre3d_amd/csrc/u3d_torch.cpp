@@ -34,14 +34,21 @@ struct Plan {
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 // descriptors are small PODs: cache the scratch sizes per distinct descriptor (the per-view route reuses ONE shape all step long).
-// Entries are never erased: backward nodes keep a pointer to theirs (unordered_map nodes are address-stable).
-const Plan& plan_for(const u3d_raster_desc& d) {
+// Returned BY VALUE and stored by value in the autograd node (`plan_save` / `plan_load`), so the cache can be bounded: ragged
+// scene-level batches bring a new total_P almost every step.
+constexpr size_t kPlanCacheMax = 64;
+std::string desc_key(const u3d_raster_desc& d) {
+  u3d_raster_desc k = d;
+  k.item_offsets = d.item_offsets ? (const int32_t*)8 : nullptr;   // (a plan depends on whether it is set, not on where it points)
+  return std::string(reinterpret_cast<const char*>(&k), sizeof(k));
+}
+Plan plan_for(const u3d_raster_desc& d) {
   static std::mutex mu;
-  static std::unordered_map<std::string, Plan> cache;
-  std::string key(reinterpret_cast<const char*>(&d), sizeof(d));
+  static auto* cache = new std::unordered_map<std::string, Plan>();   // (leaked on purpose: no destructor at interpreter exit)
+  std::string key = desc_key(d);
   std::lock_guard<std::mutex> lock(mu);
-  auto it = cache.find(key);
-  if (it != cache.end()) return it->second;
+  auto it = cache->find(key);
+  if (it != cache->end()) return it->second;
   Plan p{};
   p.d = d;
   const int rc = u3d_scratch_query(&p.d, &p.s);
@@ -49,33 +56,52 @@ const Plan& plan_for(const u3d_raster_desc& d) {
   p.o_binning = align256(p.s.geom_bytes);
   p.o_image = p.o_binning + align256(p.s.binning_bytes);
   p.fwd_scratch = p.o_image + align256(p.s.image_bytes);
-  return cache.emplace(std::move(key), p).first->second;
+  if (cache->size() >= kPlanCacheMax) cache->clear();
+  cache->emplace(std::move(key), p);
+  return p;
+}
+inline std::string plan_save(const Plan& p) { return std::string(reinterpret_cast<const char*>(&p), sizeof(Plan)); }
+inline Plan plan_load(const std::string& bytes) {
+  Plan p{};
+  TORCH_CHECK(bytes.size() == sizeof(Plan), "corrupt plan record");
+  std::memcpy(&p, bytes.data(), sizeof(Plan));
+  return p;
 }
 
-// Backward scratch kept per (device, stream, shape): a backward call leaves its gradient accumulators zero, so the next call on
-// the same stream with the same shape is told not to clear them again (U3D_FLAG_ACC_CLEAN) -- no allocation and one launch less
-// per call.  Calls on one stream are ordered, so one scratch per stream is enough; `clean` is dropped while a call is in flight on
-// the host so that a failed call cannot leave a stale promise behind.
-struct Workspace { Tensor buf; bool clean = false; };
-using WsKey = std::tuple<int, void*, const Plan*, const void*>;   // device, stream, shape, ragged layout (offsets pointer) or null
+// Backward scratch: ONE grow-only buffer per (device, stream).  A call that completes leaves its gradient accumulators zero, so
+// the next call on the same stream WITH THE SAME DESCRIPTOR SHAPE (another shape carves the buffer differently) is told not to
+// clear them again (U3D_FLAG_ACC_CLEAN) -- no allocation and one launch less per call.  Ragged batches, whose total changes
+// every step, share the buffer without the promise; nothing is keyed on a tensor's address and nothing accumulates.
+// The fused step holds its lease from the autograd forward to the autograd backward: a second forward in between (or a node
+// dropped without backward) finds the lease outstanding and takes a fresh buffer, so a pending backward never loses its data.
+struct Workspace { Tensor buf; std::string clean_key; bool outstanding = false; uint64_t ticket = 0; };
+struct Lease { Tensor buf; bool clean; uint64_t ticket; };
+using WsKey = std::pair<int, void*>;   // device, stream
 std::mutex g_ws_mu;
-std::map<WsKey, Workspace> g_ws;
-// takes the scratch of `key` (allocating it on first use) and withdraws its promise; returns whether the promise held
-std::pair<Tensor, bool> workspace_acquire(const WsKey& key, const at::TensorOptions& byte_opts) {
+auto* g_ws = new std::map<WsKey, Workspace>();   // (heap, never destroyed: HIP tensors must not be freed during static destruction)
+uint64_t g_ws_ticket = 0;
+Lease workspace_acquire(const WsKey& key, const Plan& plan, const std::string& shape_key, const at::TensorOptions& byte_opts) {
   std::lock_guard<std::mutex> lock(g_ws_mu);
-  auto it = g_ws.find(key);
-  if (it == g_ws.end()) {
-    if (g_ws.size() >= 16) g_ws.clear();      // shapes come and go (validation sizes, ragged scenes): keep the cache small
-    it = g_ws.emplace(key, Workspace{at::empty({(int64_t)std::get<2>(key)->s.backward_bytes}, byte_opts), false}).first;
+  Workspace& ws = (*g_ws)[key];
+  const int64_t need = (int64_t)plan.s.backward_bytes;
+  if (ws.outstanding || !ws.buf.defined() || ws.buf.numel() < need) {
+    ws.buf = at::empty({std::max<int64_t>(need, ws.buf.defined() && !ws.outstanding ? ws.buf.numel() : 0)}, byte_opts);
+    ws.clean_key.clear();
   }
-  const bool clean = it->second.clean;
-  it->second.clean = false;
-  return {it->second.buf, clean};
+  const bool clean = !ws.clean_key.empty() && ws.clean_key == shape_key;
+  ws.clean_key.clear();          // the promise is withdrawn while a call is in flight on the host: a failed call leaves none behind
+  ws.outstanding = true;
+  ws.ticket = ++g_ws_ticket;
+  return {ws.buf, clean, ws.ticket};
 }
-void workspace_release(const WsKey& key, const Tensor& buf) {   // the call succeeded: its accumulators are zero again
+// the call (or, for the fused step, its backward half) succeeded: its accumulators are zero again.  zeroed = false: the lease
+// ends without that promise (the backward half was skipped).
+void workspace_release(const WsKey& key, uint64_t ticket, const std::string& shape_key, bool zeroed = true) {
   std::lock_guard<std::mutex> lock(g_ws_mu);
-  auto it = g_ws.find(key);
-  if (it != g_ws.end() && it->second.buf.is_same(buf)) it->second.clean = true;
+  auto it = g_ws->find(key);
+  if (it == g_ws->end() || it->second.ticket != ticket || !it->second.outstanding) return;
+  it->second.outstanding = false;
+  if (zeroed) it->second.clean_key = shape_key;
 }
 
 inline const float* fptr(const Tensor& t) { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; }
@@ -146,17 +172,17 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     d.tanfovx = (float)tanfovx; d.tanfovy = (float)tanfovy; d.scale_modifier = (float)scale_modifier;
     d.sh_degree = (int32_t)sh_degree; d.sh_coeffs = (int32_t)M; d.flags = (int32_t)flags;
     d.total_P = (int32_t)total_P;
-    d.item_offsets = ragged ? (const int32_t*)8 : nullptr;     // (the plan depends on whether it is set, not on where it points)
-    const Plan& plan = plan_for(d);
-    u3d_raster_desc dd = plan.d;                               // this call's descriptor: the plan's shape + the device pointer
-    dd.item_offsets = ragged ? offsets.data_ptr<int32_t>() : nullptr;
+    d.item_offsets = ragged ? offsets.data_ptr<int32_t>() : nullptr;
+    const Plan plan = plan_for(d);
+    u3d_raster_desc dd = d;                                    // this call's descriptor: the plan's shape + the device pointer
     const int64_t NV = n_items * vpi;
     const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
     Tensor color = single ? at::empty({3, H, W}, fopt) : at::empty({NV, 3, H, W}, fopt);
     Tensor invdepth = single ? at::empty({1, H, W}, fopt) : at::empty({NV, 1, H, W}, fopt);
-    // (every (view, Gaussian) radius is written by the projection kernel)
+    // (every (view, Gaussian) radius is written by the projection kernel; a ragged batch starts from zeros so that pairs a
+    // malformed prefix-sum table leaves unprojected read as culled instead of as uninitialised memory)
     Tensor radii = single ? at::empty({P}, fopt.dtype(at::kInt))
-                          : (ragged ? at::empty({vpi * total_P}, fopt.dtype(at::kInt)) : at::empty({NV, P}, fopt.dtype(at::kInt)));
+                          : (ragged ? at::zeros({vpi * total_P}, fopt.dtype(at::kInt)) : at::empty({NV, P}, fopt.dtype(at::kInt)));
     Tensor arena = at::empty({(int64_t)plan.fwd_scratch}, fopt.dtype(at::kByte));   // geom | binning | image
     char* base = (char*)arena.data_ptr();
     const int rc = u3d_rasterize_forward(&dd, fptr(bg), fptr(means3D), fptr(shs), fptr(colors), fptr(opac), fptr(scales), fptr(rots),
@@ -164,7 +190,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                                          P > 0 ? radii.data_ptr<int32_t>() : nullptr, base, base + plan.o_binning, base + plan.o_image,
                                          current_stream(dev));
     TORCH_CHECK(rc == U3D_OK, "u3d_rasterize_forward failed: ", u3d_error_string(rc), " (code ", rc, ")");
-    ctx->saved_data["plan"] = (int64_t)(intptr_t)&plan;      // (cache entries are never moved: unordered_map nodes are stable)
+    ctx->saved_data["plan"] = plan_save(plan);
     ctx->saved_data["has_colors"] = colors.defined();
     ctx->saved_data["single"] = single;
     ctx->saved_data["has_means2D"] = means2D_.has_value() && means2D_->defined();
@@ -175,7 +201,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    const Plan& plan = *(const Plan*)(intptr_t)ctx->saved_data["plan"].toInt();
+    const Plan plan = plan_load(ctx->saved_data["plan"].toStringRef());
     const bool has_colors = ctx->saved_data["has_colors"].toBool();
     const bool single = ctx->saved_data["single"].toBool();
     const bool has_m2d = ctx->saved_data["has_means2D"].toBool();
@@ -213,19 +239,22 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     Tensor g_cov = cov.defined() ? out(false, {6}) : Tensor();
     if (live) {
       void* stream = current_stream(dev);
-      const WsKey key{(int)dev.index(), stream, &plan, ragged ? (const void*)offsets.data_ptr() : nullptr};
-      auto [scratch, clean] = workspace_acquire(key, fopt.dtype(at::kByte));
+      const WsKey key{(int)dev.index(), stream};
+      const std::string shape_key = desc_key(plan.d);
+      const Lease lease = workspace_acquire(key, plan, shape_key, fopt.dtype(at::kByte));
+      const Tensor& scratch = lease.buf;
       u3d_raster_desc dd = plan.d;
       dd.item_offsets = ragged ? offsets.data_ptr<int32_t>() : nullptr;
-      if (clean) dd.flags |= U3D_FLAG_ACC_CLEAN;
+      if (lease.clean) dd.flags |= U3D_FLAG_ACC_CLEAN;
       const char* base = (const char*)arena.data_ptr();
       const int rc = u3d_rasterize_backward(&dd, fptr(bg), fptr(means3D), fptr(shs), fptr(colors), fptr(opac), fptr(scales), fptr(rots),
                                             fptr(cov), fptr(view), fptr(proj), fptr(campos), radii.data_ptr<int32_t>(), fptr(gcol), fptr(ginv),
                                             base, base + plan.o_binning, base + plan.o_image, scratch.data_ptr(), fptr_mut(g_means3D),
                                             fptr_mut(g_means2D), fptr_mut(g_shs), fptr_mut(g_col), fptr_mut(g_op), fptr_mut(g_scales),
                                             fptr_mut(g_rots), fptr_mut(g_cov), stream);
+      if (rc != U3D_OK) workspace_release(key, lease.ticket, shape_key, false);
       TORCH_CHECK(rc == U3D_OK, "u3d_rasterize_backward failed: ", u3d_error_string(rc), " (code ", rc, ")");
-      workspace_release(key, scratch);
+      workspace_release(key, lease.ticket, shape_key);
     }
     return {g_means3D, g_means2D, g_shs, g_col, g_op, g_scales, g_rots, g_cov, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
             Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
@@ -235,16 +264,20 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
 // ---- fused render-loss training step (u3d_render_loss_step): activations + render + loss + backward in one launch sequence ------
 // One call per training step, but its host cost is exposed whenever a step's kernels are short (C1, C3: 7 launches in ~0.1 ms).
 std::mutex g_unit_mu;
-std::map<int, Tensor> g_unit;
+auto* g_unit = new std::map<int, Tensor>();   // (heap, never destroyed)
 Tensor unit_tensor(int64_t device_index) {   // the cached dL/dloss = 1 of fused.backward_unit(): recognised by its storage in backward
   std::lock_guard<std::mutex> lock(g_unit_mu);
-  auto it = g_unit.find((int)device_index);
-  if (it == g_unit.end())
-    it = g_unit.emplace((int)device_index, at::ones({}, at::TensorOptions().dtype(at::kFloat).device(c10::Device(c10::kCUDA, (c10::DeviceIndex)device_index)))).first;
+  auto it = g_unit->find((int)device_index);
+  if (it == g_unit->end())
+    it = g_unit->emplace((int)device_index, at::ones({}, at::TensorOptions().dtype(at::kFloat).device(c10::Device(c10::kCUDA, (c10::DeviceIndex)device_index)))).first;
   return it->second;
 }
 
 struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
+  // forward  = u3d_render_loss_step_forward : projection [+ sort] -> single-pass tile kernel -> fixed-order reduce  => loss + accumulators
+  // backward = u3d_render_loss_step_backward: chain rule accumulators -> d(head_out), scaled IN the kernel by autograd's grad_output
+  // (a device scalar): a plain `loss.backward()` (train_network.py:333) launches the same kernels as the one-call C entry point,
+  // with no d_head * g multiply; fused.backward_unit() additionally spares autograd's ones_like fill.
   using OptTensor = c10::optional<Tensor>;
   static variable_list forward(AutogradContext* ctx, Tensor head_out, Tensor center, Tensor view, Tensor proj, Tensor campos, Tensor gt,
                                Tensor bg, int64_t H, int64_t W, double tanfov, int64_t mode, double offset_scale, int64_t sh_degree,
@@ -280,51 +313,89 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
     d.n_items = (int32_t)B; d.views_per_item = (int32_t)V; d.P = (int32_t)P; d.image_height = (int32_t)H; d.image_width = (int32_t)W;
     d.tanfovx = d.tanfovy = (float)tanfov; d.scale_modifier = (float)scale_modifier; d.sh_degree = (int32_t)sh_degree;
     d.sh_coeffs = (int32_t)K; d.flags = (int32_t)flags; d.total_P = (int32_t)total_P;
-    d.item_offsets = ragged ? (const int32_t*)8 : nullptr;
-    const Plan& plan = plan_for(d);
+    d.item_offsets = ragged ? offsets.data_ptr<int32_t>() : nullptr;
+    const Plan plan = plan_for(d);
     u3d_head_desc hd{(int32_t)mode, (int32_t)C, (float)offset_scale, isotropic ? 1 : 0};
     u3d_loss_desc ld{(int32_t)loss_kind, (float)non_bg_rate, (float)bg_rate};
     const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
     Tensor color = want_color ? at::empty({NV, 3, H, W}, fopt) : at::empty({0}, fopt);
-    Tensor radii = ragged ? at::empty({V * total_P}, fopt.dtype(at::kInt)) : at::empty({NV, P}, fopt.dtype(at::kInt));
+    Tensor radii = ragged ? at::zeros({V * total_P}, fopt.dtype(at::kInt)) : at::empty({NV, P}, fopt.dtype(at::kInt));
     Tensor loss = at::empty({}, fopt);
-    Tensor d_head = at::empty_like(head_out);
     const size_t o_fused = plan.o_image;                                 // arena: geom | binning | fused  (no image buffer in this path)
     Tensor arena = at::empty({(int64_t)(o_fused + align256(plan.s.fused_bytes))}, fopt.dtype(at::kByte));
     char* base = (char*)arena.data_ptr();
     void* stream = current_stream(dev);
-    const WsKey key{(int)dev.index(), stream, &plan, ragged ? (const void*)offsets.data_ptr() : nullptr};
-    auto [scratch, clean] = workspace_acquire(key, fopt.dtype(at::kByte));
-    u3d_raster_desc dd = plan.d;
-    dd.item_offsets = ragged ? offsets.data_ptr<int32_t>() : nullptr;
-    if (clean) dd.flags |= U3D_FLAG_ACC_CLEAN;
-    const int rc = u3d_render_loss_step(&dd, &hd, &ld, fptr(bg), fptr(head_out), fptr(center), fptr(view), fptr(proj), fptr(campos), fptr(gt),
-                                        want_color ? color.data_ptr<float>() : nullptr, radii.data_ptr<int32_t>(), loss.data_ptr<float>(),
-                                        d_head.data_ptr<float>(), base, base + plan.o_binning, base + o_fused, scratch.data_ptr(), stream);
-    TORCH_CHECK(rc == U3D_OK, "u3d_render_loss_step failed: ", u3d_error_string(rc), " (code ", rc, ")");
-    workspace_release(key, scratch);
-    ctx->save_for_backward({d_head});
+    const WsKey key{(int)dev.index(), stream};
+    const std::string shape_key = desc_key(d);
+    const Lease lease = workspace_acquire(key, plan, shape_key, fopt.dtype(at::kByte));
+    u3d_raster_desc dd = d;
+    if (lease.clean) dd.flags |= U3D_FLAG_ACC_CLEAN;
+    const int rc = u3d_render_loss_step_forward(&dd, &hd, &ld, fptr(bg), fptr(head_out), fptr(center), fptr(view), fptr(proj), fptr(campos),
+                                                fptr(gt), want_color ? color.data_ptr<float>() : nullptr, radii.data_ptr<int32_t>(),
+                                                loss.data_ptr<float>(), base, base + plan.o_binning, base + o_fused, lease.buf.data_ptr(), stream);
+    if (rc != U3D_OK) workspace_release(key, lease.ticket, shape_key, false);
+    TORCH_CHECK(rc == U3D_OK, "u3d_render_loss_step_forward failed: ", u3d_error_string(rc), " (code ", rc, ")");
+    // (the lease stays outstanding until the backward half has consumed -- and re-zeroed -- the accumulators)
+    ctx->saved_data["plan"] = plan_save(plan);
+    ctx->saved_data["head"] = std::vector<int64_t>{mode, C, isotropic ? 1 : 0};
+    ctx->saved_data["offset_scale"] = offset_scale;
+    ctx->saved_data["ticket"] = (int64_t)lease.ticket;
+    ctx->saved_data["stream"] = (int64_t)(intptr_t)stream;
+    ctx->saved_data["consumed"] = false;
+    ctx->save_for_backward({head_out, center, view, proj, campos, radii, arena, lease.buf, offsets});
     ctx->mark_non_differentiable({color, radii});
     ctx->set_materialize_grads(false);
     return {loss, color, radii};
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    const Tensor d_head = ctx->get_saved_variables()[0];
-    Tensor g;
-    if (!grads[0].defined()) g = at::zeros_like(d_head);
-    else {
-      Tensor unit;
-      {
-        std::lock_guard<std::mutex> lock(g_unit_mu);
-        auto it = g_unit.find((int)d_head.device().index());
-        if (it != g_unit.end()) unit = it->second;
-      }
-      // dL/dloss is THE unit tensor of fused.backward_unit(): nothing to scale (no ones_like fill, no d_head * 1 multiply)
-      g = (unit.defined() && grads[0].data_ptr() == unit.data_ptr()) ? d_head : d_head * grads[0];
-    }
+    const Plan plan = plan_load(ctx->saved_data["plan"].toStringRef());
+    const auto hv = ctx->saved_data["head"].toIntVector();
+    const uint64_t ticket = (uint64_t)ctx->saved_data["ticket"].toInt();
+    auto sv = ctx->get_saved_variables();
+    const Tensor &head_out = sv[0], &center = sv[1], &view = sv[2], &proj = sv[3], &campos = sv[4], &radii = sv[5], &arena = sv[6],
+                 &scratch = sv[7], &offsets = sv[8];
+    const c10::Device dev = head_out.device();
+    const WsKey key{(int)dev.index(), (void*)(intptr_t)ctx->saved_data["stream"].toInt()};
+    const std::string shape_key = desc_key(plan.d);
     variable_list out(22);
-    out[0] = g;
+    if (!grads[0].defined()) {                 // the loss was not used downstream: nothing to chain, and the accumulators stay dirty
+      workspace_release(key, ticket, shape_key, false);
+      out[0] = at::zeros_like(head_out);
+      return out;
+    }
+    TORCH_CHECK(!ctx->saved_data["consumed"].toBool(),
+                "the fused render-loss step was backpropagated a second time: its backward half consumes (and re-zeroes) the gradient "
+                "accumulators of the forward half; call render_loss_fused again (retain_graph does not apply to this node)");
+    ctx->saved_data["consumed"] = true;
+    void* stream = current_stream(dev);
+    TORCH_CHECK(stream == key.second, "the fused render-loss step must be backpropagated on the stream its forward ran on");
+    Tensor unit;
+    {
+      std::lock_guard<std::mutex> lock(g_unit_mu);
+      auto it = g_unit->find((int)dev.index());
+      if (it != g_unit->end()) unit = it->second;
+    }
+    // dL/dloss: a device scalar the projection-backward kernel multiplies in as it reads the accumulators; THE unit tensor of
+    // fused.backward_unit() (recognised by its storage) needs no load at all
+    Tensor g = grads[0];
+    const float* gptr = nullptr;
+    if (!(unit.defined() && g.data_ptr() == unit.data_ptr())) {
+      g = f32c(g, dev);
+      TORCH_CHECK(g.numel() == 1, "gradient of the scalar loss must be a scalar");
+      gptr = g.data_ptr<float>();
+    }
+    u3d_raster_desc dd = plan.d;
+    dd.item_offsets = offsets.defined() ? offsets.data_ptr<int32_t>() : nullptr;
+    u3d_head_desc hd{(int32_t)hv[0], (int32_t)hv[1], (float)ctx->saved_data["offset_scale"].toDouble(), (int32_t)hv[2]};
+    Tensor d_head = at::empty_like(head_out);
+    const char* base = (const char*)arena.data_ptr();
+    const int rc = u3d_render_loss_step_backward(&dd, &hd, fptr(head_out), fptr(center), fptr(view), fptr(proj), fptr(campos),
+                                                 radii.data_ptr<int32_t>(), gptr, base, base + plan.o_binning, (void*)(base + plan.o_image),
+                                                 scratch.data_ptr(), d_head.data_ptr<float>(), stream);
+    workspace_release(key, ticket, shape_key, rc == U3D_OK);
+    TORCH_CHECK(rc == U3D_OK, "u3d_render_loss_step_backward failed: ", u3d_error_string(rc), " (code ", rc, ")");
+    out[0] = d_head;
     return out;
   }
 };
@@ -393,8 +464,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         "fused training step (u3d_render_loss_step): loss, [images], radii; autograd's backward returns the stored d loss / d head_out");
   m.def("unit_tensor", &unit_tensor, "the cached dL/dloss = 1 tensor of a device (fused.backward_unit)");
   m.def("abi_version", []() { return u3d_abi_version(); });
-  m.def("clear_workspaces", []() { std::lock_guard<std::mutex> lock(g_ws_mu); g_ws.clear(); },
+  m.def("clear_workspaces", []() { std::lock_guard<std::mutex> lock(g_ws_mu); g_ws->clear(); },
         "drop the cached backward scratch buffers (the next backward of every shape clears its accumulators itself)");
-  m.def("workspaces", []() { std::lock_guard<std::mutex> lock(g_ws_mu); int n = 0, c = 0; for (auto& kv : g_ws) { ++n; c += kv.second.clean; } return std::make_pair(n, c); },
-        "(cached backward scratch buffers, how many of them hold the accumulators-are-zero promise)");
+  m.def("workspaces", []() {
+          std::lock_guard<std::mutex> lock(g_ws_mu);
+          int n = 0, c = 0, o = 0; int64_t bytes = 0;
+          for (auto& kv : *g_ws) { ++n; c += !kv.second.clean_key.empty(); o += kv.second.outstanding; bytes += kv.second.buf.defined() ? kv.second.buf.numel() : 0; }
+          return std::make_tuple(n, c, o, bytes);
+        },
+        "(cached backward scratch buffers -- one per (device, stream) --, how many hold the accumulators-are-zero promise, how many are "
+        "leased to a pending backward, total bytes)");
 }
