@@ -179,6 +179,27 @@ def test_scratch_query_rejects_index_overflow(lib):
     assert lib.u3d_scratch_query(ctypes.byref(fine), ctypes.byref(sizes)) == 0
 
 
+def test_ragged_layout_from_sizes_cannot_be_inconsistent():
+    """`sizes=` is the checked way to describe a ragged batch (advisor, round 2): prefix sums and the largest set are derived on
+    the host, malformed sizes are refused before anything reaches the kernels."""
+    import torch
+    from unipre3d_amd import fused
+    from unipre3d_amd.rasterizer import ragged_layout, rasterize_gaussians_batched
+    off, mp = ragged_layout([4, 0, 9, 2], torch.device("cpu"))
+    assert off.tolist() == [0, 4, 4, 13, 15] and off.dtype == torch.int32 and mp == 9
+    assert ragged_layout((4, 0, 9, 2), torch.device("cpu"))[0] is off          # cached: a repeated layout costs no copy
+    for bad in ([], [0, 0], [3, -1]):
+        with pytest.raises(ValueError):
+            ragged_layout(bad, torch.device("cpu"))
+    h = torch.zeros(15, 23)
+    with pytest.raises(ValueError):          # sizes do not add up to the packed rows
+        fused.render_loss_fused(h, torch.zeros(15, 3), torch.zeros(4, 1, 4, 4), torch.zeros(4, 1, 4, 4), torch.zeros(4, 1, 3),
+                                torch.zeros(4, 1, 3, 8, 8), torch.zeros(3), 50.0, 8, 8, level="scene", sizes=[4, 0, 9, 3])
+    with pytest.raises(ValueError):          # both forms at once
+        fused.render_loss_fused(h, torch.zeros(15, 3), torch.zeros(4, 1, 4, 4), torch.zeros(4, 1, 4, 4), torch.zeros(4, 1, 3),
+                                torch.zeros(4, 1, 3, 8, 8), torch.zeros(3), 50.0, 8, 8, level="scene", sizes=[4, 0, 9, 2], item_offsets=off, max_P=9)
+
+
 def test_ragged_host_helpers():
     """pack_ragged / split_ragged_radii / the fused route's shape checks (host logic only)."""
     import torch

@@ -323,13 +323,13 @@ def test_single_pass_step_reuses_its_workspace_with_clean_accumulators(level, P,
     for bd in batches:
         C.clear_workspaces()
         fresh.append(step(bd))
-        assert C.workspaces() == (1, 1)                          # the step left its workspace marked clean
+        assert C.workspaces()[:3] == (1, 1, 0)                   # the step left its workspace marked clean, lease returned
     C.clear_workspaces()
     for rnd in range(2):
         for bd, (l0, g0) in zip(batches, fresh):
             l1, g1 = step(bd)                                    # from the second step on: U3D_FLAG_ACC_CLEAN
             assert torch.equal(l1, l0) and torch.equal(g1, g0), (rnd, float((g1 - g0).abs().max()))
-    assert C.workspaces() == (1, 1)
+    assert C.workspaces()[:3] == (1, 1, 0)
 
 
 @pytest.mark.parametrize("level,loss_kind,P,V,H,W", [("object", "focal_l2", 128, 4, 96, 96), ("scene", "l2", 600, 2, 48, 80)])
@@ -407,7 +407,7 @@ def test_operator_backward_reuses_its_workspace_with_clean_accumulators(level, P
     for seed in (3, 4, 5):
         C.clear_workspaces()
         fresh.append(run(seed))
-        assert C.workspaces() == (1, 1)                     # one scratch, left clean
+        assert C.workspaces()[:3] == (1, 1, 0)              # one scratch, left clean
     C.clear_workspaces()
     for rnd in range(2):
         for seed, g0 in zip((3, 4, 5), fresh):
@@ -417,4 +417,92 @@ def test_operator_backward_reuses_its_workspace_with_clean_accumulators(level, P
                 assert all(rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6 for a, b in zip(g1, g0) if b.abs().sum() > 0), (rnd, seed)
             else:
                 assert all(torch.equal(a, b) for a, b in zip(g1, g0)), (rnd, seed)
-    assert C.workspaces() == (1, 1)
+    assert C.workspaces()[:3] == (1, 1, 0)
+
+
+def test_fused_step_backward_half_scales_by_grad_output_and_survives_interleaving():
+    """ABI 4: the autograd forward runs projection -> tiles -> reduce, the autograd backward runs the chain rule and multiplies by
+    autograd's grad_output INSIDE the projection-backward kernel (no d_head * g launch).  Checks: (a) loss.backward(),
+    backward_unit(loss) and (3 * loss).backward() / 3 agree (bit-identical for the first two: g = 1 is an exact multiply);
+    (b) two forwards before either backward (the second finds the scratch leased and takes its own) give the gradients of two
+    separate steps; (c) a forward whose loss is dropped does not poison the next step; (d) backward(retain_graph=True) followed by a
+    second backward works (the forward half is recomputed); (e) one scratch buffer per stream is all that is ever cached."""
+    from unipre3d_amd import fused, rasterizer
+    C = rasterizer._C()
+    _, b1 = _batch(2, 128, 2, 64, 64, level="object", seed=31)
+    _, b2 = _batch(2, 128, 2, 64, 64, level="object", seed=32)
+
+    def fwd(bd):
+        h = bd.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+        loss, _, _ = fused.render_loss_fused(h, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt, bd.bg, bd.fov_deg, 64, 64,
+                                             level="object", offset_scale=bd.offset_scale, loss_kind="focal_l2", return_images=False)
+        return h, loss
+
+    C.clear_workspaces()
+    h, l = fwd(b1); l.backward(); g_plain = h.grad.clone()
+    h, l = fwd(b1); fused.backward_unit(l); g_unit = h.grad.clone()
+    h, l = fwd(b1); (3.0 * l).backward(); g_3 = h.grad.clone() / 3.0
+    h, l = fwd(b2); l.backward(); g2_ref = h.grad.clone()
+    assert torch.equal(g_plain, g_unit)
+    assert rel_l2(g_3.cpu().numpy(), g_plain.cpu().numpy()) < 1e-6
+    assert C.workspaces()[:3] == (1, 1, 0)
+    # (b) interleaved
+    ha, la = fwd(b1)
+    hb, lb = fwd(b2)
+    assert C.workspaces()[2] == 1                       # the cached buffer is leased to the second forward; the first keeps its own
+    la.backward(); lb.backward()
+    assert torch.equal(ha.grad, g_plain) and torch.equal(hb.grad, g2_ref)
+    assert C.workspaces()[:3] == (1, 1, 0)
+    # (c) dropped loss
+    hd, ld = fwd(b1)
+    del hd, ld
+    h, l = fwd(b2); l.backward()
+    assert torch.equal(h.grad, g2_ref)
+    h, l = fwd(b1); l.backward()
+    assert torch.equal(h.grad, g_plain)
+    # (d) second backward
+    h, l = fwd(b1)
+    l.backward(retain_graph=True)
+    assert torch.equal(h.grad, g_plain)
+    h.grad = None
+    (2.0 * l).backward()
+    assert rel_l2(h.grad.cpu().numpy() / 2.0, g_plain.cpu().numpy()) < 1e-6
+    assert C.workspaces()[:3] == (1, 1, 0)
+    # (e)
+    n, clean, out, nbytes = C.workspaces()
+    assert n == 1 and out == 0
+
+
+def test_ragged_steps_share_one_scratch_and_never_accumulate():
+    """Ragged scene-level batches bring a new total almost every step: the binding keeps ONE grow-only backward scratch per
+    (device, stream) -- no buffer per distinct total, no promise across shapes -- and results equal a fresh-workspace run."""
+    from unipre3d_amd import fused, rasterizer, synthetic
+    C = rasterizer._C()
+    dev = torch.device("cuda:0")
+    V, H, W = 2, 48, 64
+
+    def step(sizes, seed):
+        bs = [synthetic.make_batch(1, n, V, H, W, level="scene", seed=seed + i).to(dev) for i, n in enumerate(sizes)]
+        hp = torch.cat([b.raw[0].t() for b in bs]).contiguous().requires_grad_(True)
+        cat = lambda k: torch.cat([getattr(b, k) for b in bs])
+        loss, _, radii = fused.render_loss_fused(hp, torch.cat([b.center[0] for b in bs]), cat("world_view"), cat("full_proj"), cat("camera_center"),
+                                                 cat("gt"), bs[0].bg, bs[0].fov_deg, H, W, level="scene", offset_scale=bs[0].offset_scale,
+                                                 loss_kind="l2", return_images=False, sizes=sizes)
+        loss.backward()
+        return loss.detach().clone(), hp.grad.clone()
+
+    shapes = [([300, 500], 1), ([700, 100, 250], 2), ([300, 500], 3), ([64, 65], 4), ([300, 500], 3)]
+    fresh = []
+    for sizes, seed in shapes:
+        C.clear_workspaces()
+        fresh.append(step(sizes, seed))
+    C.clear_workspaces()
+    peak = 0
+    for rnd in range(2):
+        for (sizes, seed), (l0, g0) in zip(shapes, fresh):
+            l1, g1 = step(sizes, seed)
+            assert torch.equal(l1, l0) and rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-6
+            n, _, out, nbytes = C.workspaces()
+            assert n == 1 and out == 0
+            peak = max(peak, nbytes)
+    assert C.workspaces()[3] == peak          # grow-only: the buffer of the largest shape, nothing else

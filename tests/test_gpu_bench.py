@@ -31,6 +31,11 @@ def test_bench_line_single_gpu_small_config():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
     assert abs(out["value"] - 8 * 5 / (out["ms_per_step"] * 5e-3)) < 1e-6 * out["value"]
+    assert out["config"]["autograd_entry"] == "loss.backward()"            # the headline is quoted on the standard entry
+    assert "frac_consumed" in r and 0 < r["frac_consumed"] <= r["frac"] and r["consumed_bytes_per_launch"] <= r["algorithmic_bytes_per_launch"]
+    assert out["config"]["list_consumption"]["instances_consumed_per_view"] <= out["config"]["num_rendered_per_view"]
+    # SCALE keys exist at every N; --no-e2e leaves the region with the exchange out, and the line says so
+    assert out["scale_ok"] is False and "skipped" in out["scale_note"] and out["rccl_ranks"] == 0
 
 
 def test_bench_self_launches_two_ranks():
@@ -43,6 +48,14 @@ def test_bench_self_launches_two_ranks():
     assert e2e["collective_backend"] == "gloo" and e2e["gradient_bytes_all_reduced_per_step"] == 4 * 29_464_215
     assert e2e["n1_same_region"]["ms_per_step"] > 0 and e2e["value"] > 0
     assert "error" not in out["train_step_with_head"], out["train_step_with_head"]
+    # SCALE-proofing: the figures of the step that contains the exchange sit at the top level of the line, and scale_ok is False
+    # here because the two ranks share one device over gloo (rccl_ranks 0 != n_gpus 2)
+    for k in ("rccl_ranks", "collective_backend", "gradient_bytes_all_reduced_per_step", "train_region_value", "n1_same_region",
+              "speedup_over_n1_same_region", "scale_ok"):
+        assert k in out, k
+    assert out["rccl_ranks"] == 0 and out["collective_backend"] == "gloo" and out["scale_ok"] is False
+    assert out["train_region_value"] == e2e["value"] and out["n1_same_region"] == e2e["n1_same_region"]["value"]
+    assert out["gradient_bytes_all_reduced_per_step"] == 4 * 29_464_215 and out["speedup_over_n1_same_region"] > 0
     # the same launch quoting the step WITH the exchange in it as `value`
     out2 = _run(["--gpus", "2", "--config", "C1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--value-region", "train"],
                 env={"U3D_BENCH_SHARE_GPU": "1", "U3D_BENCH_EXTRAS_BUDGET_S": "240"})

@@ -140,6 +140,38 @@ def test_ragged_argument_errors():
         fused._batch_shape(h, torch.zeros(3, dtype=torch.int32, device="cuda"), 0)
 
 
+def test_malformed_prefix_sums_are_refused_in_debug_mode_and_harmless_otherwise():
+    """The kernels trust `item_offsets`.  With debug=True the table is checked on the device before anything is launched
+    (U3D_ERR_INVALID_ARGUMENT -> RuntimeError); without it a set that claims more than max_P Gaussians is truncated to max_P
+    (u3d_set_span) and its unprojected pairs read as culled (radii start from zeros) -- finite results, no out-of-bounds access."""
+    from unipre3d_amd import fused, synthetic
+    dev = torch.device("cuda:0")
+    V, H, W = 2, 32, 32
+    bs = [synthetic.make_batch(1, n, V, H, W, level="scene", seed=70 + n).to(dev) for n in (300, 500)]
+    cat = lambda k: torch.cat([getattr(b, k) for b in bs])
+    hp = torch.cat([b.raw[0].t() for b in bs]).contiguous()
+    args = (torch.cat([b.center[0] for b in bs]), cat("world_view"), cat("full_proj"), cat("camera_center"), cat("gt"), bs[0].bg, bs[0].fov_deg, H, W)
+    kw = dict(level="scene", offset_scale=bs[0].offset_scale, loss_kind="l2")
+    good = torch.tensor([0, 300, 800], dtype=torch.int32, device=dev)
+    for off, max_P in ((torch.tensor([0, 300, 800], dtype=torch.int32, device=dev), 400),      # largest set understated
+                       (torch.tensor([0, 500, 300], dtype=torch.int32, device=dev), 500),      # not monotone
+                       (torch.tensor([5, 300, 800], dtype=torch.int32, device=dev), 500),      # does not start at 0
+                       (torch.tensor([0, 300, 790], dtype=torch.int32, device=dev), 500)):     # does not end at the total
+        for sp in (True, False):
+            with pytest.raises(RuntimeError, match="invalid argument"):
+                fused.render_loss_fused(hp.clone().requires_grad_(True), *args, single_pass=sp, item_offsets=off, max_P=max_P, debug=True, **kw)
+    l_ok, _, _ = fused.render_loss_fused(hp.clone().requires_grad_(True), *args, item_offsets=good, max_P=500, debug=True, **kw)
+    # understated largest set without debug: the second set is rendered from its first 400 Gaussians, the rest read as culled
+    h = hp.clone().requires_grad_(True)
+    l, img, radii = fused.render_loss_fused(h, *args, item_offsets=good, max_P=400, **kw)
+    l.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(l) and torch.isfinite(img).all() and torch.isfinite(h.grad).all()
+    # (the truncated set's pairs are laid out with P_i = 400: [V * 300, V * 300 + V * 400) written, the tail untouched zeros)
+    assert radii[V * 300: V * 700].any() and not radii[V * 700:].any()
+    assert h.grad[300:700].any() and not h.grad[700:].any()
+
+
 @pytest.mark.parametrize("single_pass", [True, False])
 def test_isotropic_head_variant(single_pass):
     """cfg.model.isotropic (model/gaussian_predictor.py:308-310): scaling[:, :1].expand(-1, 3, -1) -- the first scaling channel

@@ -342,7 +342,8 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
     ctx->saved_data["ticket"] = (int64_t)lease.ticket;
     ctx->saved_data["stream"] = (int64_t)(intptr_t)stream;
     ctx->saved_data["consumed"] = false;
-    ctx->save_for_backward({head_out, center, view, proj, campos, radii, arena, lease.buf, offsets});
+    ctx->saved_data["loss"] = std::vector<double>{(double)loss_kind, non_bg_rate, bg_rate};
+    ctx->save_for_backward({head_out, center, view, proj, campos, radii, arena, lease.buf, offsets, gt, bg});
     ctx->mark_non_differentiable({color, radii});
     ctx->set_materialize_grads(false);
     return {loss, color, radii};
@@ -351,10 +352,11 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const Plan plan = plan_load(ctx->saved_data["plan"].toStringRef());
     const auto hv = ctx->saved_data["head"].toIntVector();
-    const uint64_t ticket = (uint64_t)ctx->saved_data["ticket"].toInt();
+    uint64_t ticket = (uint64_t)ctx->saved_data["ticket"].toInt();
     auto sv = ctx->get_saved_variables();
     const Tensor &head_out = sv[0], &center = sv[1], &view = sv[2], &proj = sv[3], &campos = sv[4], &radii = sv[5], &arena = sv[6],
-                 &scratch = sv[7], &offsets = sv[8];
+                 &offsets = sv[8], &gt = sv[9], &bg = sv[10];
+    Tensor scratch = sv[7];
     const c10::Device dev = head_out.device();
     const WsKey key{(int)dev.index(), (void*)(intptr_t)ctx->saved_data["stream"].toInt()};
     const std::string shape_key = desc_key(plan.d);
@@ -364,12 +366,31 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
       out[0] = at::zeros_like(head_out);
       return out;
     }
-    TORCH_CHECK(!ctx->saved_data["consumed"].toBool(),
-                "the fused render-loss step was backpropagated a second time: its backward half consumes (and re-zeroes) the gradient "
-                "accumulators of the forward half; call render_loss_fused again (retain_graph does not apply to this node)");
-    ctx->saved_data["consumed"] = true;
     void* stream = current_stream(dev);
     TORCH_CHECK(stream == key.second, "the fused render-loss step must be backpropagated on the stream its forward ran on");
+    u3d_raster_desc dd = plan.d;
+    dd.item_offsets = offsets.defined() ? offsets.data_ptr<int32_t>() : nullptr;
+    u3d_head_desc hd{(int32_t)hv[0], (int32_t)hv[1], (float)ctx->saved_data["offset_scale"].toDouble(), (int32_t)hv[2]};
+    const char* base = (const char*)arena.data_ptr();
+    if (ctx->saved_data["consumed"].toBool()) {
+      // backward(retain_graph=True) followed by another backward: the first one consumed (and re-zeroed) the accumulators, so the
+      // forward half is run again into a fresh lease -- same inputs, same arena, identical results; the rare path pays a recompute,
+      // the hot path keeps nothing alive for it
+      const auto lv = ctx->saved_data["loss"].toDoubleVector();
+      u3d_loss_desc ld{(int32_t)lv[0], (float)lv[1], (float)lv[2]};
+      const Lease lease = workspace_acquire(key, plan, shape_key, at::TensorOptions().dtype(at::kByte).device(dev));
+      u3d_raster_desc d2 = dd;
+      if (lease.clean) d2.flags |= U3D_FLAG_ACC_CLEAN;
+      Tensor loss_again = at::empty({}, at::TensorOptions().dtype(at::kFloat).device(dev));
+      const int rc2 = u3d_render_loss_step_forward(&d2, &hd, &ld, fptr(bg), fptr(head_out), fptr(center), fptr(view), fptr(proj), fptr(campos),
+                                                   fptr(gt), nullptr, radii.data_ptr<int32_t>(), loss_again.data_ptr<float>(), (void*)base,
+                                                   (void*)(base + plan.o_binning), (void*)(base + plan.o_image), lease.buf.data_ptr(), stream);
+      if (rc2 != U3D_OK) workspace_release(key, lease.ticket, shape_key, false);
+      TORCH_CHECK(rc2 == U3D_OK, "u3d_render_loss_step_forward (recompute) failed: ", u3d_error_string(rc2), " (code ", rc2, ")");
+      scratch = lease.buf;
+      ticket = lease.ticket;
+    }
+    ctx->saved_data["consumed"] = true;
     Tensor unit;
     {
       std::lock_guard<std::mutex> lock(g_unit_mu);
@@ -385,11 +406,9 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
       TORCH_CHECK(g.numel() == 1, "gradient of the scalar loss must be a scalar");
       gptr = g.data_ptr<float>();
     }
-    u3d_raster_desc dd = plan.d;
-    dd.item_offsets = offsets.defined() ? offsets.data_ptr<int32_t>() : nullptr;
-    u3d_head_desc hd{(int32_t)hv[0], (int32_t)hv[1], (float)ctx->saved_data["offset_scale"].toDouble(), (int32_t)hv[2]};
-    Tensor d_head = at::empty_like(head_out);
-    const char* base = (const char*)arena.data_ptr();
+    // (every row is written by the projection-backward kernel; a ragged batch starts from zeros so that rows a malformed prefix-sum
+    // table leaves out read as zero gradient instead of as uninitialised memory)
+    Tensor d_head = offsets.defined() ? at::zeros_like(head_out) : at::empty_like(head_out);
     const int rc = u3d_render_loss_step_backward(&dd, &hd, fptr(head_out), fptr(center), fptr(view), fptr(proj), fptr(campos),
                                                  radii.data_ptr<int32_t>(), gptr, base, base + plan.o_binning, (void*)(base + plan.o_image),
                                                  scratch.data_ptr(), d_head.data_ptr<float>(), stream);

@@ -62,7 +62,7 @@ class _RenderLossFn(torch.autograd.Function):
         dev = head_out.device
         if grad_loss is None and grad_color is None:
             return (torch.zeros_like(head_out),) + (None,) * 20
-        d_head = torch.empty_like(head_out)
+        d_head = torch.zeros_like(head_out) if ctx.item_offsets is not None else torch.empty_like(head_out)
         scratch = torch.empty(ctx.plan.sizes.backward_bytes, dtype=torch.uint8, device=dev)
         dloss = _f32c(grad_loss, dev).reshape(1) if grad_loss is not None else torch.zeros(1, dtype=torch.float32, device=dev)
         extra = None
@@ -109,7 +109,7 @@ def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: 
                       non_bg_color_loss_rate: float = 4.0, bg_color_loss_rate: float = 1.0, input_images: int = 0,
                       scaling_modifier: float = 1.0, antialiasing: bool = True, debug: bool = False,
                       single_pass: bool = True, return_images: bool = True, differentiable_images: bool = False,
-                      isotropic: bool = False, item_offsets: torch.Tensor = None, max_P: int = 0):
+                      isotropic: bool = False, item_offsets: torch.Tensor = None, max_P: int = 0, sizes=None):
     """head_out (B,P,C) point-major raw head output (C = 23 at SH degree 1), center (B,P,3), cameras (B,Vtot,...),
     gt (B,Vtot,3,H,W).  Returns (loss scalar, rendered (B*V',3,H,W), radii (B*V',P)).
     single_pass (default): when a gradient is wanted, forward and backward run as ONE launch sequence
@@ -121,9 +121,18 @@ def render_loss_fused(head_out: torch.Tensor, center: torch.Tensor, world_view: 
     dL/d(rendered) to the in-kernel loss seed (u3d_render_loss_backward's dL_dcolor_extra): still one launch sequence each way.
     isotropic: cfg.model.isotropic (the first scaling channel serves all three axes, model/gaussian_predictor.py:308-310).
     Ragged batches (the scene-level branch's per-item lists, model/gaussian_predictor.py:331-364): head_out (sum P_i, C) and center
-    (sum P_i, 3) PACKED in set order, item_offsets int32 (B+1,) prefix sums on the device (rasterizer.pack_ragged), max_P the largest
-    set; radii then come back packed (V' * sum P_i,) -- one launch sequence for sets of different sizes."""
+    (sum P_i, 3) PACKED in set order and `sizes` = the sets' sizes on the host (rasterizer.pack_ragged returns them; the prefix sums
+    and the largest set are derived here, so they cannot be inconsistent); radii then come back packed (V' * sum P_i,) -- one launch
+    sequence for sets of different sizes.  (Expert form: item_offsets int32 (B+1,) on the device + max_P, trusted by the kernels and
+    checked on the device only with debug=True.)"""
     dev = head_out.device
+    if sizes is not None:
+        if item_offsets is not None:
+            raise ValueError("pass either sizes or item_offsets / max_P, not both")
+        if head_out.dim() != 2 or sum(int(n) for n in sizes) != head_out.shape[0]:
+            raise ValueError(f"ragged batch: head_out must be packed (sum P_i, C) with sum P_i = {sum(sizes)}")
+        from .rasterizer import ragged_layout
+        item_offsets, max_P = ragged_layout(sizes, dev)
     B = head_out.shape[0] if item_offsets is None else item_offsets.numel() - 1
     wv, fp, cc = world_view[:, input_images:], full_proj[:, input_images:], camera_center[:, input_images:]
     NV = B * wv.shape[1]

@@ -94,6 +94,31 @@ def pack_ragged(tensors, device=None):
     return torch.cat(list(tensors), dim=0), torch.tensor(off, dtype=torch.int32, device=dev), sizes
 
 
+_layout_cache = {}
+
+
+def ragged_layout(sizes, device):
+    """Host-side sizes of the sets -> (item_offsets int32 (n+1,) on `device`, max_P).  This is the checked way to describe a
+    ragged batch: the prefix sums are built here from the sizes (monotone, first 0, last sum, largest set = max_P by
+    construction), so the kernels' trust in `item_offsets` is never misplaced; the entry points take `sizes=` and call this.
+    Recent layouts are kept (a training loop cycles through few of them) so that a repeated layout costs no H2D copy."""
+    sizes = tuple(int(n) for n in sizes)
+    if not sizes or min(sizes) < 0 or max(sizes) <= 0:
+        raise ValueError(f"ragged batch: set sizes must be non-negative with at least one non-empty set, got {sizes}")
+    key = (sizes, str(device))
+    hit = _layout_cache.get(key)
+    if hit is None:
+        off = [0]
+        for n in sizes:
+            off.append(off[-1] + n)
+        if off[-1] >= 1 << 31:
+            raise ValueError("ragged batch: more than 2^31 Gaussians")
+        if len(_layout_cache) >= 64:
+            _layout_cache.clear()
+        hit = _layout_cache[key] = (torch.tensor(off, dtype=torch.int32, device=device), max(sizes))
+    return hit
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -154,16 +179,18 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 def rasterize_gaussians_batched(means3D, opacities, viewmatrix, projmatrix, campos, bg, image_height, image_width, tanfovx,
                                 tanfovy, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
                                 sh_degree=0, scale_modifier=1.0, antialiasing=True, debug=False, exact_aa_grad=False,
-                                means2D=None, item_offsets=None, max_P=0):
+                                means2D=None, item_offsets=None, max_P=0, sizes=None):
     """B sets x V cameras in ONE launch sequence.
     means3D (B,P,3), opacities (B,P,1), shs (B,P,M,3) | colors_precomp (B,P,3), scales (B,P,3) + rotations (B,P,4) |
     cov3D_precomp (B,P,6); viewmatrix/projmatrix (B,V,4,4), campos (B,V,3), bg (3,).
     means2D (B*V,P,3), optional: the per-view screen-space gradient sink (`viewspace_points` of
     gaussian_renderer/__init__.py:29); its .grad receives dL/dmean2D.
     Returns color (B,V,3,H,W), radii (B,V,P) int32, invdepth (B,V,1,H,W).
-    Ragged batch (item_offsets int32 (B+1,) on the device, max_P = largest set; see `pack_ragged`): every per-Gaussian tensor is
-    PACKED (sum P_i, ...) in set order; radii come back packed (V * sum P_i,), the pairs of set i and view v starting at
-    V * item_offsets[i] + v * P_i (`split_ragged_radii`), means2D is (V * sum P_i, 3) in the same layout."""
+    Ragged batch (`sizes` = the sets' sizes on the host, as `pack_ragged` returns them): every per-Gaussian tensor is PACKED
+    (sum P_i, ...) in set order; radii come back packed (V * sum P_i,), the pairs of set i and view v starting at
+    V * item_offsets[i] + v * P_i (`split_ragged_radii`), means2D is (V * sum P_i, 3) in the same layout.  (Expert form:
+    item_offsets int32 (B+1,) already on the device + max_P = largest set; the kernels TRUST those -- checked on the device only
+    with debug=True -- whereas `sizes` cannot be inconsistent.)"""
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
     if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -173,6 +200,12 @@ def rasterize_gaussians_batched(means3D, opacities, viewmatrix, projmatrix, camp
     if dev.type != "cuda":
         raise RuntimeError("the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback "
                            "(the CPU restatement lives in oracle/ and is test infrastructure only)")
+    if sizes is not None:
+        if item_offsets is not None:
+            raise ValueError("pass either sizes or item_offsets / max_P, not both")
+        if sum(int(n) for n in sizes) != means3D.shape[0]:
+            raise ValueError(f"ragged batch: sizes sum to {sum(sizes)} but {means3D.shape[0]} Gaussians are packed")
+        item_offsets, max_P = ragged_layout(sizes, dev)
     ragged = item_offsets is not None
     B = item_offsets.numel() - 1 if ragged else means3D.shape[0]
     P = int(max_P) if ragged else means3D.shape[1]
