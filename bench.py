@@ -202,7 +202,54 @@ def e2e_region(a, batch, dev, world, rank, B, V, H, W, loss_kind, timed):
     if solo:
         out["n1_same_region"] = solo
         out["speedup_over_n1_same_region"] = out["value"] / solo["value"]
+    if rank == 0:
+        try:
+            out["gradclip_n4b"] = gradclip_region(net, nparam)
+        except Exception as e:  # noqa: BLE001
+            out["gradclip_n4b"] = {"error": repr(e)[:300]}
     return out
+
+
+def gradclip_region(net, nparam, reps=20):
+    """N4(b) on the stand-in predictor's own gradient set (29.46 M fp32 values in a few hundred tensors, as left by the last
+    step): the reference's formulation (per-parameter isnan / isinf scans with their host syncs + clip_grad_norm_,
+    train_network.py:368-390), the HIP multi-tensor pass with its single 32-byte host read, and its host-read-free form."""
+    from unipre3d_amd import gradcheck
+    params = [p for p in net.parameters() if p.grad is not None]
+    keep = [p.grad.clone() for p in params]
+
+    def restore():
+        for p, g in zip(params, keep):
+            p.grad.copy_(g)
+
+    def ref():
+        bad = any(torch.isnan(p.grad).any() or torch.isinf(p.grad).any() for p in params)
+        if not bad:
+            torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
+        return not bad
+
+    opt = torch.optim.AdamW(params, lr=0.0, fused=True)
+    res = {}
+    for name, fn in (("reference_formulation", ref), ("hip_one_host_read", lambda: gradcheck.check_and_clip_gradients(params, 1.0)),
+                     ("hip_no_host_read", lambda: gradcheck.check_and_clip_deferred(params, opt, 1.0))):
+        for _ in range(3):
+            restore(); fn()
+        tot = 0.0
+        for _ in range(reps):
+            restore()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            tot += time.perf_counter() - t0
+        res[name + "_ms"] = 1e3 * tot / reps
+    st = gradcheck.gradient_state(params, 1.0)
+    restore()
+    res.update({"tensors": len(params), "values": nparam, "total_norm": st["total_norm"], "clipping_live": st["coef"] < 1.0,
+                "bytes_read_stats_pass": 4 * nparam,
+                "what": "wall time of one check-and-clip on the stand-in's gradients incl. launch + sync (the pass itself reads 118 MB once: "
+                        "~15 us at 8 TB/s, so every variant is latency-, not bandwidth-bound)"})
+    return res
 
 
 def per_view_region(batch, B, P, V, H, W, loss_kind, steps=5):

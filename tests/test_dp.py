@@ -45,6 +45,25 @@ def test_single_process_helpers():
     assert sum(p.numel() for p in h.parameters()) == 384 * 128 + 128 + 128 * 23 + 23   # 52,247
 
 
+def test_gradclip_library_exports_every_declared_symbol():
+    """include/unipre3d_gradclip.h vs libunipre3d_gradclip.so (no compute without a GPU: argument checks only)."""
+    import ctypes, os, re
+    from unipre3d_amd import gradcheck
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "unipre3d_gradclip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(u3d_[a-z_0-9]+)\s*\(", hdr)))
+    assert set(names) == set(gradcheck.EXPORTS)
+    lib = gradcheck.load()
+    null = ctypes.c_void_p(0)
+    assert lib.u3d_gradclip_stats(null, null, null, 0, 0, null, null) == 0          # nothing to do
+    assert lib.u3d_gradclip_stats(null, null, null, 3, 5, null, null) == 1          # missing tables
+    assert lib.u3d_gradclip_stats(null, null, null, -1, 0, null, null) == 1
+    assert lib.u3d_gradclip_finalize(null, 0, ctypes.c_float(1.0), null, null) == 1  # no state block
+    assert lib.u3d_gradclip_scale(null, null, null, 2, 2, null, null) == 1
+    assert int(re.search(r"#define U3D_GC_CHUNK (\d+)", open(os.path.join(root, "include", "unipre3d_gradclip.h")).read()).group(1)) == gradcheck.GC_CHUNK
+
+
 def test_check_and_clip_gradients_matches_reference_semantics():
     """train_network.py:368-390: False on any NaN/Inf (grads untouched), else clip_grad_norm_(max_norm=1.0)."""
     from unipre3d_amd.gradcheck import check_and_clip_gradients

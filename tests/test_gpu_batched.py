@@ -506,3 +506,121 @@ def test_ragged_steps_share_one_scratch_and_never_accumulate():
             assert n == 1 and out == 0
             peak = max(peak, nbytes)
     assert C.workspaces()[3] == peak          # grow-only: the buffer of the largest shape, nothing else
+
+
+def _clip_reference(grads, max_norm):
+    """train_network.py:368-390 on copies: (valid, clipped gradients)."""
+    ps = [torch.nn.Parameter(torch.zeros_like(g)) for g in grads]
+    for p, g in zip(ps, grads):
+        p.grad = g.clone()
+    bad = any(bool(torch.isnan(p.grad).any() or torch.isinf(p.grad).any()) for p in ps)
+    if bad:
+        return False, [p.grad for p in ps]
+    torch.nn.utils.clip_grad_norm_(ps, max_norm=max_norm)
+    return True, [p.grad for p in ps]
+
+
+@pytest.mark.parametrize("case", ["large", "small", "nan", "inf", "neg_inf", "overflow", "bucket_views", "many"])
+def test_gradclip_kernels_match_reference_semantics(case):
+    """N4(b): the multi-tensor HIP pass (csrc/u3d_gradclip.hip) against the reference's own two statements --
+    the per-parameter isnan / isinf scan and torch.nn.utils.clip_grad_norm_(max_norm=1.0) (train_network.py:376-389):
+    clipping when the norm exceeds 1, identity (bit-exact) below it, skip-step on NaN / +Inf / -Inf with the gradients left
+    untouched, finite gradients whose fp32 sum of squares overflows, DDP-style bucket views at odd 4-byte offsets, and a few
+    hundred tensors of every size around the 64 K-element chunk and the 16-byte vector boundary."""
+    import math
+    from unipre3d_amd import gradcheck
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(dev)
+    flat = None
+    if case == "many":
+        sizes = [1, 2, 3, 4, 5, 63, 64, 65, 1023, 4096, 65535, 65536, 65537, 131072, 200001, 384, 0] * 12
+        grads = [mk(n, s=0.01) for n in sizes]
+    elif case == "bucket_views":
+        flat = mk(300000, s=0.05)
+        offs, grads = 1, []                       # views at element offsets 1, 779, ...: every 4-byte alignment class
+        for n in (777, 65536, 3, 100001, 2):
+            grads.append(flat[offs:offs + n]); offs += n + 1
+    elif case == "small":
+        grads = [mk(384, 128, s=1e-4), mk(128, s=1e-4), mk(23, 128, s=1e-4)]
+    else:
+        grads = [mk(384, 128), mk(128), mk(70000), mk(23, 128)]
+    if case == "nan":
+        grads[2][12345] = float("nan")
+    if case == "inf":
+        grads[0][3, 7] = float("inf")
+    if case == "neg_inf":
+        grads[3][22, 127] = float("-inf")
+    if case == "overflow":
+        grads[2].mul_(1e19)                        # finite values, fp32 sum of squares = inf
+    before = [x.clone() for x in grads]
+    flat_before = flat.clone() if flat is not None else None
+    ps = [torch.nn.Parameter(torch.zeros_like(x)) for x in grads]
+    for p, x in zip(ps, grads):
+        p.grad = x                                 # (bucket views are clipped in place inside the flat buffer)
+    ok_ref, ref = _clip_reference(before, 1.0)
+    st = gradcheck.gradient_state(ps, 1.0)
+    ok = gradcheck.check_and_clip_gradients(ps, 1.0)
+    torch.cuda.synchronize()
+    if case == "overflow":
+        # the reference's fp32 total norm is inf here -> clip_grad_norm_ zeroes everything; the f64 norm stays finite and the
+        # gradients are scaled to unit norm (what clip_grad_norm_ does for any finite norm)
+        assert ok and math.isfinite(st["total_norm"]) and st["total_norm"] > 1e19
+        tot = math.sqrt(sum(float((p.grad.double() ** 2).sum()) for p in ps))
+        assert abs(tot - 1.0) < 1e-5
+        return
+    assert ok == ok_ref and st["found_inf"] == (not ok_ref)
+    if not ok_ref:
+        nn = lambda x: x.nan_to_num(7.0, 8.0, 9.0)
+        assert all(torch.equal(nn(p.grad), nn(b)) for p, b in zip(ps, before))      # untouched
+        return
+    tot_ref = math.sqrt(sum(float((b.double() ** 2).sum()) for b in before))
+    assert abs(st["total_norm"] - tot_ref) <= 1e-9 * max(tot_ref, 1.0)
+    assert st["amax"] == max(float(b.abs().max()) for b in before if b.numel())
+    if case == "small":
+        assert st["coef"] == 1.0 and all(torch.equal(p.grad, b) for p, b in zip(ps, before))       # below max_norm: bit-identical
+    else:
+        assert st["coef"] < 1.0
+    for p, r in zip(ps, ref):
+        if p.numel():
+            assert rel_l2(p.grad.cpu().numpy(), r.cpu().numpy()) < 1e-6
+    if flat is not None:        # the elements between the views are not ours to touch
+        mask = torch.ones_like(flat, dtype=torch.bool)
+        offs = 1
+        for n in (777, 65536, 3, 100001, 2):
+            mask[offs:offs + n] = False; offs += n + 1
+        assert torch.equal(flat[mask], flat_before[mask])
+
+
+def test_gradclip_deferred_drives_fused_adamw_without_a_host_read():
+    """check_and_clip_deferred: found_inf stays on the device; AdamW(fused=True) skips the step exactly when the reference's
+    `if not valid: skip` would, and otherwise steps on the clipped gradients -- same parameters as the host-read route."""
+    from unipre3d_amd import gradcheck
+    dev = torch.device("cuda:0")
+
+    def run(deferred, poison):
+        torch.manual_seed(3)
+        m = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 23)).to(dev)
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-2, fused=True)
+        x = torch.randn(512, 64, generator=torch.Generator().manual_seed(1)).to(dev)
+        out = []
+        for it in range(4):
+            opt.zero_grad(set_to_none=False)
+            (m(x) ** 2).sum().backward()                     # norm >> 1: clipping is live
+            if poison and it == 1:
+                m[0].weight.grad[5, 5] = float("nan")
+            if deferred:
+                gradcheck.check_and_clip_deferred(m.parameters(), opt, 1.0)
+                opt.step()
+            elif gradcheck.check_and_clip_gradients(m.parameters(), 1.0):
+                opt.step()
+            out.append([p.detach().clone() for p in m.parameters()])
+        return out
+
+    for poison in (False, True):
+        a, b = run(False, poison), run(True, poison)
+        for it, (pa, pb) in enumerate(zip(a, b)):
+            assert all(torch.isfinite(x).all() for x in pb), (poison, it)
+            assert all(rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 1e-6 for x, y in zip(pa, pb)), (poison, it)
+        if poison:      # iteration 1 was skipped: parameters equal those after iteration 0
+            assert all(torch.equal(x, y) for x, y in zip(b[0], b[1]))
