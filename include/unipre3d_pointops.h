@@ -17,6 +17,15 @@
  *   u3d_group_points[_grad]      <- group_points[_grad]_wrapper(b, c, n, npoints, nsample, points (B,C,N), idx, out (B,C,npoints,nsample))
  *   u3d_gather_points[_grad]     <- gather_points[_grad]_wrapper(b, c, n, npoints, points (B,C,N), idx (B,npoints), out (B,C,npoints))
  *        The *_grad forms ACCUMULATE into grad_points (B,C,N) with float atomics; zero it first like the reference does.
+ *   u3d_three_nn                 <- three_nn_wrapper(b, n, m, unknown (B,N,3), known (B,M,3), dist2 (B,N,3), idx (B,N,3))
+ *        (pointnet2_api.cpp:21, interpolate_gpu.cu:16-59) squared distances and indices of the three nearest known points of
+ *        every unknown point, ascending; ties keep the lower index (the reference's strict `<` insertions in index order);
+ *        with fewer than three known points the unfilled slots hold the reference's initial 1e40 (stored as +inf) and index 0.
+ *   u3d_three_interpolate        <- three_interpolate_wrapper(b, c, m, n, points (B,C,M), idx (B,N,3), weight (B,N,3), out (B,C,N))
+ *        (:22, interpolate_gpu.cu:84-103) out[b][c][i] = sum_k weight[b][i][k] * points[b][c][idx[b][i][k]].
+ *   u3d_three_interpolate_grad   <- three_interpolate_grad_wrapper(b, c, n, m, grad_out (B,C,N), idx, weight, grad_points (B,C,M))
+ *        (:23, interpolate_gpu.cu:127-148) ACCUMULATES grad_out * weight into grad_points with float atomics; zero it first
+ *        (openpoints/models/layers/upsampling.py:86).
  */
 #ifndef UNIPRE3D_POINTOPS_H
 #define UNIPRE3D_POINTOPS_H
@@ -35,6 +44,11 @@ int u3d_group_points_grad(int b, int c, int n, int npoints, int nsample, const f
 int u3d_gather_points(int b, int c, int n, int npoints, const float* points, const int32_t* idx, float* out, void* stream);
 int u3d_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out, const int32_t* idx, float* grad_points,
                            void* stream);
+int u3d_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2, int32_t* idx, void* stream);
+int u3d_three_interpolate(int b, int c, int m, int n, const float* points, const int32_t* idx, const float* weight, float* out,
+                          void* stream);
+int u3d_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out, const int32_t* idx, const float* weight,
+                               float* grad_points, void* stream);
 
 #ifdef __cplusplus
 }

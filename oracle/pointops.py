@@ -77,3 +77,25 @@ def gather_points_grad(grad_out, idx, N):
     g = np.zeros((B, C, N), np.float32)
     _load().po_gather_points_grad(B, C, int(N), M, _p(grad_out), _p(idx), _p(g))
     return g
+
+
+def three_nn(unknown, known):
+    """-> (dist2 (B,N,3) float32 SQUARED distances as the kernel writes them, idx (B,N,3) int32)."""
+    unknown, known = _f(unknown), _f(known); B, N, _ = unknown.shape; M = known.shape[1]
+    d2 = np.zeros((B, N, 3), np.float32); idx = np.zeros((B, N, 3), np.int32)
+    _load().po_three_nn(B, N, M, _p(unknown), _p(known), _p(d2), _p(idx))
+    return d2, idx
+
+
+def three_interpolate(points, idx, weight):
+    points, idx, weight = _f(points), _i(idx), _f(weight); B, C, M = points.shape; N = idx.shape[1]
+    out = np.zeros((B, C, N), np.float32)
+    _load().po_three_interpolate(B, C, M, N, _p(points), _p(idx), _p(weight), _p(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, M):
+    grad_out, idx, weight = _f(grad_out), _i(idx), _f(weight); B, C, N = grad_out.shape
+    g = np.zeros((B, C, int(M)), np.float32)
+    _load().po_three_interpolate_grad(B, C, N, int(M), _p(grad_out), _p(idx), _p(weight), _p(g))
+    return g

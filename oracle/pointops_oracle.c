@@ -10,6 +10,8 @@
  *   ball_query                src/ball_query_gpu.cu:15-51   (idx zero-initialised: layers/group.py:192)
  *   group_points (+grad)      src/group_points_gpu.cu:53-72, 14-31
  *   gather_points (+grad)     src/sampling_gpu.cu:15-31, 53-70
+ *   three_nn                  src/interpolate_gpu.cu:16-59
+ *   three_interpolate (+grad) src/interpolate_gpu.cu:84-103, 127-148
  * The reference sources are CUDA (no nvcc, no NVIDIA device here) and ship no test vectors, so this restatement is
  * "parity unpinned" against the reference BINARY; it is pinned to the reference SOURCE by construction: the
  * simulated thread loop / shared-memory tree below is the kernel's own control flow executed sequentially.
@@ -136,4 +138,64 @@ void po_gather_points_grad(int b, int c, int n, int m, const float* grad_out, co
     for (int ci = 0; ci < c; ++ci)
       for (int p = 0; p < m; ++p)
         grad_points[((size_t)bi * c + ci) * n + idx[(size_t)bi * m + p]] += grad_out[((size_t)bi * c + ci) * m + p];
+}
+
+/* interpolate_gpu.cu:16-59: one simulated thread per (batch, unknown point); `double` bests initialised to 1e40, strict `<`
+ * insertions while scanning the known points in index order; results stored as float / int. */
+void po_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2v, int* idx) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int p = 0; p < n; ++p) {
+      const float* u = unknown + ((size_t)bi * n + p) * 3;
+      const float* kn = known + (size_t)bi * m * 3;
+      const float ux = u[0], uy = u[1], uz = u[2];
+      double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+      int besti1 = 0, besti2 = 0, besti3 = 0;
+      for (int k = 0; k < m; ++k) {
+        const float x = kn[k * 3 + 0], y = kn[k * 3 + 1], z = kn[k * 3 + 2];
+        /* (ux-x)*(ux-x) + (uy-y)*(uy-y) + (uz-z)*(uz-z), contracted left to right like the other distances of this file */
+        const float d = fmaf(uz - z, uz - z, fmaf(uy - y, uy - y, (ux - x) * (ux - x)));
+        if (d < best1) {
+          best3 = best2; besti3 = besti2;
+          best2 = best1; besti2 = besti1;
+          best1 = d; besti1 = k;
+        } else if (d < best2) {
+          best3 = best2; besti3 = besti2;
+          best2 = d; besti2 = k;
+        } else if (d < best3) {
+          best3 = d; besti3 = k;
+        }
+      }
+      float* od = dist2v + ((size_t)bi * n + p) * 3;
+      int* oi = idx + ((size_t)bi * n + p) * 3;
+      od[0] = (float)best1; od[1] = (float)best2; od[2] = (float)best3;
+      oi[0] = besti1; oi[1] = besti2; oi[2] = besti3;
+    }
+}
+
+/* interpolate_gpu.cu:84-103 ; weight[0]*p[idx0] + weight[1]*p[idx1] + weight[2]*p[idx2] contracted left to right */
+void po_three_interpolate(int b, int c, int m, int n, const float* points, const int* idx, const float* weight, float* out) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci)
+      for (int p = 0; p < n; ++p) {
+        const float* w = weight + ((size_t)bi * n + p) * 3;
+        const int* ix = idx + ((size_t)bi * n + p) * 3;
+        const float* row = points + ((size_t)bi * c + ci) * m;
+        out[((size_t)bi * c + ci) * n + p] = fmaf(w[2], row[ix[2]], fmaf(w[1], row[ix[1]], w[0] * row[ix[0]]));
+      }
+}
+
+/* interpolate_gpu.cu:127-148 (three atomicAdds per thread); grad_points zero-initialised by the caller (upsampling.py:86) */
+void po_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out, const int* idx, const float* weight,
+                               float* grad_points) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci)
+      for (int p = 0; p < n; ++p) {
+        const float g = grad_out[((size_t)bi * c + ci) * n + p];
+        const float* w = weight + ((size_t)bi * n + p) * 3;
+        const int* ix = idx + ((size_t)bi * n + p) * 3;
+        float* row = grad_points + ((size_t)bi * c + ci) * m;
+        row[ix[0]] += g * w[0];
+        row[ix[1]] += g * w[1];
+        row[ix[2]] += g * w[2];
+      }
 }

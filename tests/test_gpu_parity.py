@@ -334,6 +334,29 @@ def test_g8_analytic_known_answers(golden):
     print("g8 analytic:", {k: f"{v:.1e}" for k, v in rep.items()})
 
 
+def test_g9_general_known_answers(golden):
+    """The HIP operator against the general known answers (tests/golden/make_g9_general.py): off-axis means, rotated anisotropic
+    covariances, non-unit quaternion, active clamp, 4:3 image with one FOV, SH degree 2-3, rectangle culling, FD gradients."""
+    from g9_cases import run_g9
+    from unipre3d_amd.rasterizer import GaussianRasterizationSettings, rasterize_gaussians
+    dev = torch.device("cuda:0")
+
+    def render(means, scales, rots, opac, shs, view, proj, campos, bg, H, W, t, deg, aa, dcol):
+        T = lambda a, grad=False: torch.tensor(np.asarray(a, dtype=np.float32), device=dev).requires_grad_(grad)
+        m, s, q, o, sh = T(means, True), T(scales, True), T(rots, True), T(opac, True), T(shs, True)
+        st = GaussianRasterizationSettings(H, W, t, t, T(bg), 1.0, T(view), T(proj), deg, T(campos), False, True, aa)
+        color, radii, _ = rasterize_gaussians(m, torch.zeros_like(m), sh, None, o, s, q, None, st)
+        gr = None
+        if dcol is not None:
+            (color * T(dcol)).sum().backward()
+            gr = {"means3D": m.grad.cpu().numpy(), "scales": s.grad.cpu().numpy(), "opacities": o.grad.cpu().numpy(),
+                  "rotations": q.grad.cpu().numpy(), "shs": sh.grad.cpu().numpy()}
+        return color.detach().cpu().numpy(), radii.cpu().numpy(), gr
+
+    rep = run_g9(golden("g9_general.npz"), render)
+    print("g9 general:", {k: f"{v:.1e}" for k, v in rep.items()})
+
+
 def test_operator_refuses_inconsistent_shapes():
     """The C-ABI trusts its sizes; the binding refuses tensors whose shapes do not add up (upstream raises on means3D not (P, 3))."""
     from unipre3d_amd.rasterizer import GaussianRasterizer, rasterize_gaussians_batched

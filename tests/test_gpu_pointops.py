@@ -60,3 +60,42 @@ def test_transformer_tokenizer_pipeline():
     assert gx.shape == (8, 3, 128, 32) and gf.shape == (8, 3, 128, 32)
     idx = po.ball_query(0.1, 32, xyz, centers.cpu().numpy())
     assert np.array_equal(gf.cpu().numpy(), po.group_points(xyz.transpose(0, 2, 1).copy(), idx))
+
+
+@pytest.mark.parametrize("B,N,M,grid", [(4, 1024, 128, False), (2, 1000, 300, True), (1, 5000, 4500, False), (2, 130, 2, False),
+                                        (1, 7, 1, False), (3, 257, 2049, True)])
+def test_three_nn_bit_exact(B, N, M, grid):
+    """interpolate_gpu.cu:16-59: squared distances and indices bit-exact against the oracle, incl. lattice clouds full of ties,
+    fewer than three known points (1e40 -> +inf, index 0) and a known cloud spanning several LDS tiles."""
+    from unipre3d_amd import pointops
+    unk, kn = _cloud(B, N, seed=N, grid=grid), _cloud(B, M, seed=M + 1, grid=grid)
+    dist, idx = pointops.three_nn(torch.from_numpy(unk).cuda(), torch.from_numpy(kn).cuda())
+    d2_ref, idx_ref = po.three_nn(unk, kn)
+    assert idx.dtype == torch.int32 and np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert np.array_equal(dist.cpu().numpy(), np.sqrt(d2_ref))            # the wrapper returns L2 distances (upsampling.py:35)
+
+
+def test_three_interpolate_forward_backward():
+    """Values bit-exact (same left-to-right contraction), scatter-add gradient to fp32 summation order; and the reference's
+    three_interpolation composite (upsampling.py:92-101) against the same chain through the oracle."""
+    from unipre3d_amd import pointops
+    rng = np.random.RandomState(11)
+    feats = rng.randn(3, 37, 200).astype(np.float32)
+    idx = rng.randint(0, 200, (3, 1000, 3)).astype(np.int32)
+    w = rng.rand(3, 1000, 3).astype(np.float32)
+    f = torch.from_numpy(feats).cuda().requires_grad_(True)
+    out = pointops.three_interpolate(f, torch.from_numpy(idx).cuda(), torch.from_numpy(w).cuda())
+    assert np.array_equal(out.detach().cpu().numpy(), po.three_interpolate(feats, idx, w))
+    go = rng.randn(*out.shape).astype(np.float32)
+    out.backward(torch.from_numpy(go).cuda())
+    gref = po.three_interpolate_grad(go, idx, w, 200)
+    assert np.abs(f.grad.cpu().numpy() - gref).max() <= 1e-5 * np.abs(gref).max()
+    # composite
+    unk, kn = _cloud(2, 500, seed=1), _cloud(2, 64, seed=2)
+    kf = rng.randn(2, 16, 64).astype(np.float32)
+    got = pointops.three_interpolation(torch.from_numpy(unk).cuda(), torch.from_numpy(kn).cuda(), torch.from_numpy(kf).cuda()).cpu().numpy()
+    d2, ix = po.three_nn(unk, kn)
+    rec = 1.0 / (torch.sqrt(torch.from_numpy(d2)) + 1e-8)
+    wt = (rec / rec.sum(dim=2, keepdim=True)).numpy()
+    ref = po.three_interpolate(kf, ix, wt)
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()

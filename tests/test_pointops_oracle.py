@@ -100,3 +100,44 @@ def test_pointops_library_exports_every_declared_symbol():
     null = ctypes.c_void_p(0)
     assert lib.u3d_furthest_point_sampling(1, 8, 2, null, null, null, null) == 1        # NULL pointers rejected
     assert lib.u3d_ball_query(0, 8, 2, ctypes.c_float(0.1), 4, null, null, null, null) == 0   # empty batch is legal
+
+
+def test_three_nn_is_the_three_smallest_distance_index_pairs():
+    """interpolate_gpu.cu:16-59: strict `<` insertions in index order = the three smallest (distance, index) pairs in
+    lexicographic order (ties keep the lower index); fewer than three known points leave 1e40 -> +inf and index 0."""
+    for grid, seed in ((False, 1), (True, 2)):
+        unk, kn = _cloud(2, 300, seed=seed, grid=grid), _cloud(2, 77, seed=seed + 10, grid=grid)
+        d2, idx = po.three_nn(unk, kn)
+        for b in range(2):
+            dx = unk[b][:, None, :] - kn[b][None, :, :]
+            # the oracle's own contraction order: fma(dz, dz, fma(dy, dy, dx * dx)) -- evaluated in float64 products rounded per step
+            f32 = np.float32
+            t = (dx[..., 0] * dx[..., 0]).astype(f32)
+            t = (dx[..., 1].astype(np.float64) * dx[..., 1] + t).astype(f32)
+            d = (dx[..., 2].astype(np.float64) * dx[..., 2] + t).astype(f32)
+            order = np.lexsort((np.arange(77)[None, :].repeat(300, 0), d), axis=1)[:, :3]
+            assert np.array_equal(idx[b], order.astype(np.int32))
+            assert np.array_equal(d2[b], np.take_along_axis(d, order, 1))
+        if grid:
+            assert (d2[..., 0] == d2[..., 1]).any()       # the lattice really produces ties
+    d2, idx = po.three_nn(_cloud(1, 5, seed=3), _cloud(1, 2, seed=4))
+    assert np.isinf(d2[..., 2]).all() and (idx[..., 2] == 0).all() and np.isfinite(d2[..., :2]).all()
+    d2, idx = po.three_nn(_cloud(1, 5, seed=3), np.zeros((1, 0, 3), np.float32))
+    assert np.isinf(d2).all() and not idx.any()
+
+
+def test_three_interpolate_definition_and_grad():
+    rng = np.random.RandomState(5)
+    feats = rng.randn(2, 6, 40).astype(np.float32)
+    idx = rng.randint(0, 40, (2, 90, 3)).astype(np.int32)
+    w = rng.rand(2, 90, 3).astype(np.float32)
+    out = po.three_interpolate(feats, idx, w)
+    ref = np.einsum("bnk,bcnk->bcn", w.astype(np.float64), np.stack([feats[b][:, idx[b]] for b in range(2)]).astype(np.float64))
+    assert out.shape == (2, 6, 90) and np.allclose(out, ref, rtol=1e-6, atol=1e-6)
+    go = rng.randn(2, 6, 90).astype(np.float32)
+    g = po.three_interpolate_grad(go, idx, w, 40)
+    gref = np.zeros((2, 6, 40))
+    for b in range(2):
+        for k in range(3):
+            np.add.at(gref[b], (slice(None), idx[b, :, k]), go[b].astype(np.float64) * w[b, :, k][None, :])
+    assert np.allclose(g, gref, rtol=1e-5, atol=1e-5)

@@ -205,6 +205,91 @@ __global__ void group_points_grad_kernel(int c, int n, int npoints, int nsample,
   unsafeAtomicAdd(&grad_points[((size_t)bi * c + ci) * n + dst], grad_out[((size_t)bi * c + ci) * npoints * nsample + e]);
 }
 
+// ---- three_nn / three_interpolate (+grad): interpolate_gpu.cu:16-140 ------------------------------------------------------
+// three_nn: the reference gives every query a thread that streams all m known points from global memory.  Here a workgroup
+// stages the known cloud through LDS in tiles (one coalesced copy per tile, then every lane reads the SAME LDS word per step:
+// a broadcast, no bank conflicts) and each lane keeps its query's running three best in registers.  Scanning in index order
+// with the reference's strict `<` insertions gives the three smallest (distance, index) pairs in lexicographic order, ties to
+// the lower index -- reproduced exactly; an unfilled slot keeps the reference's initial 1e40 (stored as +inf) / index 0.
+constexpr int NN_THREADS = 128;
+constexpr int NN_TILE = 2048;   // known points per LDS tile: 24 KB
+__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(int n, int m, const float* __restrict__ unknown,
+                                                              const float* __restrict__ known, float* __restrict__ dist2,
+                                                              int32_t* __restrict__ idx) {
+  __shared__ float s_k[NN_TILE * 3];
+  const int bi = blockIdx.y;
+  const int pt = blockIdx.x * NN_THREADS + threadIdx.x;
+  const bool live = pt < n;
+  const float* u = unknown + ((size_t)bi * n + (live ? pt : 0)) * 3;
+  const float ux = u[0], uy = u[1], uz = u[2];
+  const float* kb = known + (size_t)bi * m * 3;
+  double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+  int i1 = 0, i2 = 0, i3 = 0;
+  for (int k0 = 0; k0 < m; k0 += NN_TILE) {
+    const int cnt = min(NN_TILE, m - k0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < cnt * 3; e += NN_THREADS) s_k[e] = kb[(size_t)k0 * 3 + e];
+    __syncthreads();
+    for (int j = 0; j < cnt; ++j) {
+      const float dx = ux - s_k[j * 3], dy = uy - s_k[j * 3 + 1], dz = uz - s_k[j * 3 + 2];
+      const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));   // (ux-x)^2 + (uy-y)^2 + (uz-z)^2 as nvcc contracts it
+      const int k = k0 + j;
+      if (d < best1) { best3 = best2; i3 = i2; best2 = best1; i2 = i1; best1 = d; i1 = k; }
+      else if (d < best2) { best3 = best2; i3 = i2; best2 = d; i2 = k; }
+      else if (d < best3) { best3 = d; i3 = k; }
+    }
+  }
+  if (live) {
+    float* od = dist2 + ((size_t)bi * n + pt) * 3;
+    int32_t* oi = idx + ((size_t)bi * n + pt) * 3;
+    od[0] = (float)best1; od[1] = (float)best2; od[2] = (float)best3;
+    oi[0] = i1; oi[1] = i2; oi[2] = i3;
+  }
+}
+
+// three_interpolate: the reference launches one thread per (batch, channel, point), so every channel re-reads the point's three
+// indices and weights.  Here a lane owns a point, loads them once and walks IC_CH channels: three gathers from the channel's
+// row of m values (cache-resident) and one coalesced store per channel.  out = w0 p[i0] + w1 p[i1] + w2 p[i2], contracted
+// left to right like nvcc does (fma(w2, p2, fma(w1, p1, w0 p0))).
+constexpr int IC_CH = 8;
+__global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, int n, const float* __restrict__ points,
+                                                                const int32_t* __restrict__ idx, const float* __restrict__ weight,
+                                                                float* __restrict__ out) {
+  const int bi = blockIdx.z, c0 = blockIdx.y * IC_CH;
+  const int pt = blockIdx.x * 256 + threadIdx.x;
+  if (pt >= n) return;
+  const int32_t* ip = idx + ((size_t)bi * n + pt) * 3;
+  const float* wp = weight + ((size_t)bi * n + pt) * 3;
+  const int i0 = ip[0], i1 = ip[1], i2 = ip[2];
+  const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+  const int c1 = min(c, c0 + IC_CH);
+  for (int ci = c0; ci < c1; ++ci) {
+    const float* row = points + ((size_t)bi * c + ci) * m;
+    out[((size_t)bi * c + ci) * n + pt] = fmaf(w2, row[i2], fmaf(w1, row[i1], w0 * row[i0]));
+  }
+}
+
+__global__ __launch_bounds__(256) void three_interpolate_grad_kernel(int c, int n, int m, const float* __restrict__ grad_out,
+                                                                     const int32_t* __restrict__ idx,
+                                                                     const float* __restrict__ weight,
+                                                                     float* __restrict__ grad_points) {
+  const int bi = blockIdx.z, c0 = blockIdx.y * IC_CH;
+  const int pt = blockIdx.x * 256 + threadIdx.x;
+  if (pt >= n) return;
+  const int32_t* ip = idx + ((size_t)bi * n + pt) * 3;
+  const float* wp = weight + ((size_t)bi * n + pt) * 3;
+  const int i0 = ip[0], i1 = ip[1], i2 = ip[2];
+  const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+  const int c1 = min(c, c0 + IC_CH);
+  for (int ci = c0; ci < c1; ++ci) {
+    const float g = grad_out[((size_t)bi * c + ci) * n + pt];
+    float* row = grad_points + ((size_t)bi * c + ci) * m;
+    unsafeAtomicAdd(row + i0, g * w0);
+    unsafeAtomicAdd(row + i1, g * w1);
+    unsafeAtomicAdd(row + i2, g * w2);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -275,6 +360,38 @@ int u3d_gather_points(int b, int c, int n, int npoints, const float* points, con
 int u3d_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out, const int32_t* idx, float* grad_points,
                            void* stream) {
   return u3d_group_points_grad(b, c, n, npoints, 1, grad_out, idx, grad_points, stream);
+}
+
+int u3d_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2, int32_t* idx, void* stream) {
+  if (b < 0 || n < 0 || m < 0) return 1;
+  if (b == 0 || n == 0) return 0;
+  if (b > 65535) return 1;
+  if (!unknown || (m > 0 && !known) || !dist2 || !idx) return 1;
+  hipLaunchKernelGGL(three_nn_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS, b), dim3(NN_THREADS), 0, (hipStream_t)stream, n, m, unknown,
+                     known, dist2, idx);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int u3d_three_interpolate(int b, int c, int m, int n, const float* points, const int32_t* idx, const float* weight, float* out,
+                          void* stream) {
+  if (b < 0 || c < 0 || m < 0 || n < 0) return 1;
+  if (b == 0 || c == 0 || n == 0) return 0;
+  if (b > 65535 || (c + IC_CH - 1) / IC_CH > 65535) return 1;
+  if (!points || !idx || !weight || !out) return 1;
+  hipLaunchKernelGGL(three_interpolate_kernel, dim3((n + 255) / 256, (c + IC_CH - 1) / IC_CH, b), dim3(256), 0, (hipStream_t)stream, c, m,
+                     n, points, idx, weight, out);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int u3d_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out, const int32_t* idx, const float* weight,
+                               float* grad_points, void* stream) {
+  if (b < 0 || c < 0 || m < 0 || n < 0) return 1;
+  if (b == 0 || c == 0 || n == 0) return 0;
+  if (b > 65535 || (c + IC_CH - 1) / IC_CH > 65535) return 1;
+  if (!grad_out || !idx || !weight || !grad_points) return 1;
+  hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3((n + 255) / 256, (c + IC_CH - 1) / IC_CH, b), dim3(256), 0, (hipStream_t)stream,
+                     c, n, m, grad_out, idx, weight, grad_points);
+  return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
 }  // extern "C"

@@ -1,7 +1,7 @@
 """Point sampling / grouping operators with the reference's Python names and signatures:
 openpoints/models/layers/subsample.py:77-148 (`furthest_point_sample`, `gather_operation`, `fps`) and
-openpoints/models/layers/group.py:76-203 (`grouping_operation`, `ball_query`), and the `QueryAndGroup` module
-(:208-260).  Backed by libunipre3d_pointops.so (include/unipre3d_pointops.h); no CPU fallback."""
+openpoints/models/layers/group.py:76-203 (`grouping_operation`, `ball_query`), the `QueryAndGroup` module
+(:208-260), and openpoints/models/layers/upsampling.py:11-101 (`three_nn`, `three_interpolate`, `three_interpolation`).  Backed by libunipre3d_pointops.so (include/unipre3d_pointops.h); no CPU fallback."""
 from __future__ import annotations
 
 import ctypes
@@ -16,7 +16,7 @@ from . import _lib
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunipre3d_pointops.so")
 EXPORTS = ("u3d_furthest_point_sampling", "u3d_ball_query", "u3d_group_points", "u3d_group_points_grad",
-           "u3d_gather_points", "u3d_gather_points_grad")
+           "u3d_gather_points", "u3d_gather_points_grad", "u3d_three_nn", "u3d_three_interpolate", "u3d_three_interpolate_grad")
 _po = None
 
 
@@ -33,6 +33,9 @@ def load() -> ctypes.CDLL:
         lib.u3d_group_points_grad.argtypes = [i, i, i, i, i, vp, vp, vp, vp]
         lib.u3d_gather_points.argtypes = [i, i, i, i, vp, vp, vp, vp]
         lib.u3d_gather_points_grad.argtypes = [i, i, i, i, vp, vp, vp, vp]
+        lib.u3d_three_nn.argtypes = [i, i, i, vp, vp, vp, vp, vp]
+        lib.u3d_three_interpolate.argtypes = [i, i, i, i, vp, vp, vp, vp, vp]
+        lib.u3d_three_interpolate_grad.argtypes = [i, i, i, i, vp, vp, vp, vp, vp]
         for n in EXPORTS:
             getattr(lib, n).restype = ctypes.c_int
         _po = lib
@@ -181,6 +184,68 @@ class BallQuery(Function):
 
 
 ball_query = BallQuery.apply
+
+
+class ThreeNN(Function):
+    @staticmethod
+    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """unknown (B,N,3), known (B,M,3) -> (dist (B,N,3) L2 distances to the three nearest known points, idx (B,N,3) int32)
+        (upsampling.py:11-35; the kernel returns squared distances, the wrapper takes the root like the reference)."""
+        assert unknown.is_contiguous() and known.is_contiguous()
+        dev = _need_gpu(unknown, known)
+        unknown, known = _f32(unknown, "unknown"), _f32(known, "known")
+        B, N, _ = unknown.size()
+        m = known.size(1)
+        dist2 = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+        idx = torch.empty(B, N, 3, dtype=torch.int32, device=dev)
+        _check(load().u3d_three_nn(B, N, m, _lib.ptr(unknown), _lib.ptr(known), _lib.ptr(dist2), _lib.ptr(idx), _stream(dev)), "three_nn")
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        """features (B,C,M), idx (B,n,3), weight (B,n,3) -> (B,C,n) (upsampling.py:43-67; inputs are cast to fp32 like the
+        reference's custom_fwd(cast_inputs=torch.float32))."""
+        assert features.is_contiguous() and idx.is_contiguous() and weight.is_contiguous()
+        dev = _need_gpu(features, idx, weight)
+        features, idx, weight = _f32(features, "features"), _i32(idx, "idx"), _f32(weight, "weight")
+        B, c, m = features.size()
+        n = idx.size(1)
+        ctx.three_interpolate_for_backward = (idx, weight, m)
+        out = torch.empty(B, c, n, dtype=torch.float32, device=dev)
+        _check(load().u3d_three_interpolate(B, c, m, n, _lib.ptr(features), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(out), _stream(dev)),
+               "three_interpolate")
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, weight, m = ctx.three_interpolate_for_backward
+        B, c, n = grad_out.size()
+        grad_features = torch.zeros(B, c, m, dtype=torch.float32, device=grad_out.device)
+        g = _f32(grad_out, "grad_out").contiguous()
+        _check(load().u3d_three_interpolate_grad(B, c, n, m, _lib.ptr(g), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(grad_features),
+                                                 _stream(_need_gpu(g, idx, weight))), "three_interpolate grad")
+        return grad_features, None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+def three_interpolation(unknown_xyz, known_xyz, know_feat):
+    """Inverse-distance interpolation of `know_feat` (B,C,M) at `unknown_xyz` (B,N,3) (upsampling.py:92-101)."""
+    dist, idx = three_nn(unknown_xyz, known_xyz)
+    dist_recip = 1.0 / (dist + 1e-8)
+    norm = torch.sum(dist_recip, dim=2, keepdim=True)
+    weight = dist_recip / norm
+    return three_interpolate(know_feat, idx, weight)
 
 
 class QueryAndGroup(nn.Module):
