@@ -473,7 +473,9 @@ void FN(backward)(const oracle_state *s, const REAL *dL_dpix, const REAL *dL_din
   REAL *g_conic = (REAL *)calloc(Pn * 3, sizeof(REAL));   /* (dA, dB_half, dC) */
   REAL *g_invd = (REAL *)calloc(Pn, sizeof(REAL));
 
-  /* (1) per-tile back-to-front pass.  Thread-private accumulators, reduced afterwards. */
+  /* (1) per-tile back-to-front pass.  Thread-private accumulators, reduced afterwards.  Tiles are dealt to the threads round-robin
+   * (schedule(static, 1)): for a given thread count the fp32 summation grouping -- and with it the restatement's own distance from
+   * the fp64 arbiter, which the parity tests use as their yardstick on ill-conditioned scenes -- is the same in every run. */
   int nthreads = 1;
 #ifdef _OPENMP
   nthreads = omp_get_max_threads();
@@ -481,7 +483,7 @@ void FN(backward)(const oracle_state *s, const REAL *dL_dpix, const REAL *dL_din
   const int NG = 10; /* mean2D.xy, conic(3), opacity, rgb(3), invdepth */
   REAL *priv = (REAL *)calloc((size_t)nthreads * Pn * NG, sizeof(REAL));
   const REAL ddelx_dx = C(0.5) * (REAL)W, ddely_dy = C(0.5) * (REAL)H;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(static, 1)
   for (int tile = 0; tile < ntiles; ++tile) {
     int tid = 0;
 #ifdef _OPENMP

@@ -89,7 +89,7 @@ class _OracleRender(torch.autograd.Function):
 
 
 def head_grad_arbiter(oracle_mod, b, bi, v, H, W, n_views_total, loss_kind, dtype=np.float64, sh_degree=1,
-                      non_bg_rate=4.0, bg_rate=1.0, exact_aa_grad=False):
+                      non_bg_rate=4.0, bg_rate=1.0, exact_aa_grad=False, loss_scale=1.0):
     """d loss / d raw[bi] ((C, P), the reference's (B, 23, N) layout) where loss = render loss over ALL n_views_total views'
     pixels but only view (bi, v) differs from its target -- i.e. the per-view contribution the fused kernels can be made to
     isolate by setting gt = rendered for every other view.  Returns (gradient (C,P) ndarray, loss value, image (3,H,W))."""
@@ -115,11 +115,13 @@ def head_grad_arbiter(oracle_mod, b, bi, v, H, W, n_views_total, loss_kind, dtyp
     # the loss of this one view, re-normalised to the whole batch's pixel count (the other views contribute exact zeros)
     loss = losses.render_loss(img[None], gt[None], loss_kind, white_background=white, non_bg_color_loss_rate=non_bg_rate,
                               bg_color_loss_rate=bg_rate) / n_views_total
-    loss.backward()
-    return raw.grad[0].numpy().copy(), float(loss.item()), img.detach().numpy().copy()
+    # loss_scale != 1: backpropagate loss_scale * loss and divide the gradient again -- the same mathematics under a different
+    # rounding, i.e. a second sample of what fp32 arithmetic can resolve on this workload
+    (loss * loss_scale).backward()
+    return raw.grad[0].numpy().copy() / loss_scale, float(loss.item()), img.detach().numpy().copy()
 
 
-def head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, dtype=np.float64, sh_degree=1, input_images=0):
+def head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, dtype=np.float64, sh_degree=1, input_images=0, loss_scale=1.0):
     """d loss / d raw for the WHOLE batch ((B, C, P)): the per-view arbiters summed over every item's views (small shapes only:
     one oracle render per view).  Also returns the loss value."""
     B, V = b.raw.shape[0], b.world_view.shape[1] - input_images
@@ -127,7 +129,7 @@ def head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, dtype=np.float64, sh_d
     for bi in range(B):
         acc = None
         for v in range(input_images, input_images + V):
-            g, l, _ = head_grad_arbiter(oracle_mod, b, bi, v, H, W, B * V, loss_kind, dtype, sh_degree)
+            g, l, _ = head_grad_arbiter(oracle_mod, b, bi, v, H, W, B * V, loss_kind, dtype, sh_degree, loss_scale=loss_scale)
             acc = g if acc is None else acc + g
             loss += l
         out.append(acc)
@@ -147,3 +149,10 @@ def assert_radii(rd, r32, r64=None, what=""):
         return 0, 0
     r64 = np.asarray(r64)
     return int((rd != r64).sum()), int((r32 != r64).sum())
+
+
+def worst_fp32_sample(samples, o64):
+    """Of several fp32 evaluations of the same quantity (different roundings: dL/dloss scale, summation order), the one farthest
+    from the fp64 arbiter: the honest measure of what fp32 can resolve on an ill-conditioned workload (scene-level gradients
+    cancel ~1000 x across tiles; a single multi-threaded evaluation of the restatement lands anywhere between 4e-5 and 2e-4)."""
+    return max(samples, key=lambda a: rel_l2(a, o64))

@@ -158,6 +158,11 @@ def test_fused_render_loss_equals_unfused_path(oracle_mod, level, loss_kind, P, 
     # reference loss); scene-level gradients cancel ~1000x across tiles, there the fp32 restatement's own gap sets the bar
     a32, l32 = head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, np.float32)
     a64, l64 = head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, np.float64)
+    if level == "scene":
+        # the HIP routes are evaluated under two roundings below (dL/dloss = 1 and 3); so is the fp32 restatement, and the bar uses
+        # its worse sample (measured on this draw: HIP 3e-5 ... 2.1e-4 over four scales, restatement 4e-5 ... 1.9e-4 run to run)
+        from arbiter import worst_fp32_sample
+        a32 = worst_fp32_sample([a32, head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, np.float32, loss_scale=3.0)[0]], a64)
     assert abs(loss_f.item() - l64) <= 1e-5 * max(1.0, abs(l64))
     if loss_kind != "l1":    # (L1's gradient is discontinuous where a pixel equals its target: value / image bar only)
         tr = lambda x: x.permute(0, 2, 1).cpu().numpy()

@@ -112,18 +112,21 @@ def test_radix_sort_far_depths(oracle_mod, F, P):
         assert near(g[k].reshape(go[k].shape), go[k], go64[k]), k
 
 
-@pytest.mark.parametrize("n_dense", [800, 3000])
-def test_large_P_sort_dense_depth_bucket(oracle_mod, n_dense):
-    """The large-P sort partitions by the leading depth bits and sorts each bucket in one workgroup: in LDS (<= 1024 keys) or through
-    global ping-pong buffers (more).  A slab of `n_dense` Gaussians at almost the same depth (relative spread 1e-3, with exact
-    ties) lands in one or two buckets and takes the first (800) / second (3000) route."""
+@pytest.mark.parametrize("n_dense,spread", [(50, 1e-3), (200, 1e-3), (800, 1e-3), (3000, 1e-3), (900, 1e-7), (1500, 0.0)])
+def test_large_P_sort_dense_depth_bucket(oracle_mod, n_dense, spread):
+    """The large-P sort partitions by the leading depth bits (unordered, atomics) and one workgroup per bucket puts the bucket's
+    pairs into 256 sub-bins and RANKS every pair by (key, index) inside its sub-bin; a bucket beyond the LDS capacity (2048) or
+    with a sub-bin of more than 512 pairs takes stable radix passes over (index, key) instead, in LDS (<= 1024 keys) or through the
+    global ping-pong buffers.  A slab of `n_dense` Gaussians at almost the same depth (relative spread `spread`, with exact ties --
+    which must come out in index order whatever order the atomics produced) takes each route: 50 / 200 / 800 rank path,
+    3000 global radix, 900 within a few ulps -> one oversized sub-bin -> LDS radix, 1500 exactly equal -> global radix."""
     H, W = 64, 80
     sc = scene(6000, H, W, seed=12, level="scene", compact=True, deg=1)
     V = sc["viewmatrix"].double()
     fwd = V[:3, 2]                                                # d(depth)/d(position)
     z = torch.cat([sc["means3D"].double(), torch.ones(6000, 1, dtype=torch.float64)], 1) @ V[:, 2]
     g = torch.Generator().manual_seed(5)
-    target = 2.5 * (1.0 + 1e-3 * torch.rand(n_dense, generator=g, dtype=torch.float64))
+    target = 2.5 * (1.0 + spread * torch.rand(n_dense, generator=g, dtype=torch.float64))
     target[::7] = target[0]                                       # exact ties inside the slab
     idx = torch.arange(100, 100 + n_dense)
     sc["means3D"][idx] += ((target - z[idx])[:, None] * fwd[None, :]).float()

@@ -26,6 +26,9 @@
 #define U3D_RADIX_IT_LARGE 4
 #endif
 static inline int u3d_radix_tile(int P) { return P <= 65536 ? U3D_RADIX_NT_SMALL * U3D_RADIX_IT_SMALL : U3D_RADIX_NT_LARGE * U3D_RADIX_IT_LARGE; }
+#define U3D_MSD_BINS_MAX 1024          /* depth buckets of the large-P sort's first partition (u3d_sort.hip): 512, or 1024 beyond 64 k per view */
+static inline int u3d_msd_bins(int P) { return P <= 65536 ? 512 : 1024; }
+#define U3D_MSD_KEY_BASE 0x3E4CCCCDu   /* bits of 0.2f */
 
 // Per-call view of the carved scratch buffers (device pointers; built on the host).
 struct U3DBuffers {
@@ -37,13 +40,16 @@ struct U3DBuffers {
   uint2* rect;        // [NV*P]   x: xmin | ymin<<16 ; y: xmax | ymax<<16   (tile units)
   uint32_t* clamped;  // [NV*P]   bit c set: colour channel c clamped at 0; U3D_TOUCHED_BIT: the backward handed it a gradient
   uint32_t* num_rendered;  // [NV] sum of tiles touched (statistics only)
+  // one bit per Gaussian of the call (index gbase + i): some view handed it a gradient.  Cleared by preprocess_fwd, set by the
+  // gradient reduction, read by preprocess_bwd's wave triage -- one word per 32 Gaussians instead of 8 bytes per (view, Gaussian)
+  uint32_t* touched_words;
   // binning
   uint32_t* sorted_id;   // [NV*P] Gaussian index (within the set) in front-to-back order
   uint2* sorted_rect;    // [NV*P] rect of sorted_id[k]
   uint32_t* n_vis;       // [NV]   number of entries of the sorted list that are on screen
   uint32_t* sort_keys[2];  // [NV*P] x2  radix ping-pong (large P only)
   uint32_t* sort_vals[2];  // [NV*P] x2
-  uint32_t* sort_hist;     // per-block bucket histograms [NV][blocks][512]
+  uint32_t* sort_hist;     // bucket totals [NV][512] (zeroed by preprocess_fwd), then per-workgroup slice offsets [NV][blocks][512]
   uint32_t* sort_over;     // bucket start table [NV][513]
   // image
   float* final_T;        // [NV*H*W]
@@ -67,6 +73,13 @@ __device__ __forceinline__ void u3d_set_span(const U3DSpan& s, int item, int& Pi
   // than indexed past the grids and LDS arrays that were sized from desc.P)
   if (s.off) { const int o0 = s.off[item]; Pi = min(max(s.off[item + 1] - o0, 0), s.P); gbase = (size_t)o0; }
   else { Pi = s.P; gbase = (size_t)item * s.P; }
+}
+__device__ __forceinline__ size_t u3d_view_gbase(const U3DSpan& s, int view) {   // first Gaussian of the view's set
+  const int item = view / s.vpi;
+  return s.off ? (size_t)s.off[item] : (size_t)item * s.P;
+}
+__device__ __forceinline__ void u3d_mark_touched(uint32_t* __restrict__ words, size_t gi) {
+  atomicOr(&words[gi >> 5], 1u << (uint32_t)(gi & 31));
 }
 __device__ __forceinline__ size_t u3d_pair_base(const U3DSpan& s, int vk, int Pi, size_t gbase) {
   return (size_t)s.vpi * gbase + (size_t)vk * Pi;
@@ -174,6 +187,7 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
   CARVE(g, clamped, uint32_t, NG);
   L.num_rendered_offset = o;
   CARVE(g, num_rendered, uint32_t, NV);
+  CARVE(g, touched_words, uint32_t, (u3d_total_P(d) + 31) / 32 + 1);
   L.geom_bytes = o > 0 ? o : 256;
   o = 0;
   char* bn = (char*)binning;
@@ -186,8 +200,8 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
     CARVE(bn, sort_vals[0], uint32_t, NG);
     CARVE(bn, sort_vals[1], uint32_t, NG);
     const size_t nblk = ((size_t)d.P + u3d_radix_tile(d.P) - 1) / u3d_radix_tile(d.P);
-    CARVE(bn, sort_hist, uint32_t, NV * 512 * nblk);
-    CARVE(bn, sort_over, uint32_t, NV * 513);
+    CARVE(bn, sort_hist, uint32_t, NV * (size_t)u3d_msd_bins(d.P) * (nblk + 1));
+    CARVE(bn, sort_over, uint32_t, NV * ((size_t)u3d_msd_bins(d.P) + 1));
   } else if (b) {
     b->sort_keys[0] = b->sort_keys[1] = b->sort_vals[0] = b->sort_vals[1] = b->sort_hist = b->sort_over = nullptr;
   }
@@ -215,6 +229,8 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
 // launchers (one per translation unit)
 void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, int32_t* radii, double* acc_zero, hipStream_t s);
+// (preprocess_bwd triages by b.touched_words when d.P > U3D_LDS_SORT_MAX; the reduction kernels set the bits in that case)
+static inline bool u3d_uses_touched_words(const u3d_raster_desc& d) { return d.P > U3D_LDS_SORT_MAX; }
 void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, const int32_t* radii, const double* acc,
                                const U3DGradSink& sink, hipStream_t s, double* acc_reset = nullptr, const float* gscale = nullptr);

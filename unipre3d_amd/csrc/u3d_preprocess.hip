@@ -33,29 +33,6 @@ __device__ __forceinline__ void load_cam(Cam& c, const float* __restrict__ view,
   for (int k = 0; k < 3; ++k) c.pos[k] = campos[v * 3 + k];
 }
 
-__device__ __forceinline__ void quat_to_R(const float q[4], float R[9]) {
-  const float r = q[0], x = q[1], y = q[2], z = q[3];
-  R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
-  R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
-  R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
-}
-
-// Sigma = (R S)(R S)^T, upper triangle
-__device__ __forceinline__ void cov3d_from_scale_rot(const float s[3], float mod, const float q[4], float c6[6]) {
-  float R[9], M[9];
-  quat_to_R(q, R);
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) M[i * 3 + k] = R[i * 3 + k] * (mod * s[k]);
-  c6[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
-  c6[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
-  c6[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
-  c6[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
-  c6[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
-  c6[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
-}
-
 struct Ewa {
   float t[3];  // view-space point, x/y clamped
   float xmask, ymask;
@@ -63,38 +40,16 @@ struct Ewa {
   float fx, fy;
 };
 
-__device__ __forceinline__ void ewa_setup(Ewa& e, const float p[3], const Cam& c, float fx, float fy, float tanx,
-                                          float tany) {
-#pragma unroll
-  for (int j = 0; j < 3; ++j) e.t[j] = c.V[j] * p[0] + c.V[4 + j] * p[1] + c.V[8 + j] * p[2] + c.V[12 + j];
-  const float limx = 1.3f * tanx, limy = 1.3f * tany;
-  const float txtz = e.t[0] / e.t[2], tytz = e.t[1] / e.t[2];
-  e.xmask = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
-  e.ymask = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-  e.t[0] = fminf(limx, fmaxf(-limx, txtz)) * e.t[2];
-  e.t[1] = fminf(limy, fmaxf(-limy, tytz)) * e.t[2];
-  e.fx = fx; e.fy = fy;
-  const float tz = e.t[2];
-  const float J00 = fx / tz, J02 = -(fx * e.t[0]) / (tz * tz), J11 = fy / tz, J12 = -(fy * e.t[1]) / (tz * tz);
-  // W[j][i] = V[i*4+j]
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    e.M2[i] = J00 * c.V[i * 4 + 0] + J02 * c.V[i * 4 + 2];
-    e.M2[3 + i] = J11 * c.V[i * 4 + 1] + J12 * c.V[i * 4 + 2];
-  }
-}
-
-__device__ __forceinline__ void cov2d(const Ewa& e, const float c6[6], float abc[3]) {
-  const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
-  float MS[6];
-#pragma unroll
-  for (int k = 0; k < 2; ++k)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) MS[k * 3 + j] = e.M2[k * 3] * S[j] + e.M2[k * 3 + 1] * S[3 + j] + e.M2[k * 3 + 2] * S[6 + j];
-  abc[0] = MS[0] * e.M2[0] + MS[1] * e.M2[1] + MS[2] * e.M2[2];
-  abc[1] = MS[0] * e.M2[3] + MS[1] * e.M2[4] + MS[2] * e.M2[5];
-  abc[2] = MS[3] * e.M2[3] + MS[4] * e.M2[4] + MS[5] * e.M2[5];
-}
+namespace exact {
+#define U3D_FP_CONTRACT _Pragma("clang fp contract(off)")
+#include "u3d_proj_helpers.inc"
+#undef U3D_FP_CONTRACT
+}  // namespace exact
+namespace fast {
+#define U3D_FP_CONTRACT _Pragma("clang fp contract(fast)")
+#include "u3d_proj_helpers.inc"
+#undef U3D_FP_CONTRACT
+}  // namespace fast
 
 template <int D>
 __device__ __forceinline__ void sh_to_rgb(const float* __restrict__ sh /* [M][3] */, const float dir[3], float rgb[3],
@@ -175,7 +130,14 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     int32_t* __restrict__ radii, float* __restrict__ depth, float2* __restrict__ xy, float4* __restrict__ conic_op,
     float4* __restrict__ rgbd, uint2* __restrict__ rect, uint32_t* __restrict__ clamped,
     uint32_t* __restrict__ num_rendered, double* __restrict__ acc_zero, size_t NG, uint32_t* __restrict__ sorted_id,
-    uint2* __restrict__ sorted_rect, uint32_t* __restrict__ n_vis) {
+    uint2* __restrict__ sorted_rect, uint32_t* __restrict__ n_vis, uint32_t* __restrict__ msd_total, int msd_bins,
+    uint32_t* __restrict__ touched_words) {
+  // (msd_total != null: P > 4096; the depth sort that follows partitions by depth bucket with one global atomic per (workgroup,
+  // bucket) on these per-view totals -- the first workgroup of every (set, view slice) clears them here instead of a memset node)
+  if (msd_total && blockIdx.x == 0) {
+    const int nv0 = blockIdx.z * vpt, nv1 = min(vpi, nv0 + vpt);
+    for (int e = threadIdx.x; e < (nv1 - nv0) * msd_bins; e += U3D_BLOCK) msd_total[(size_t)(blockIdx.y * vpi + nv0) * msd_bins + e] = 0u;
+  }
   // (sorted_id != null: P <= 256, the block owns the whole set -> the per-view depth sort is fused in, see below)
   __shared__ unsigned long long s_keys[U3D_BLOCK];
   __shared__ uint2 s_rects[U3D_BLOCK];
@@ -192,6 +154,9 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
   const int v0 = blockIdx.z * vpt, v1 = min(vpi, v0 + vpt);
   U3DSource lsrc = src;
   size_t gi = gbase + (i < P ? i : 0);
+  // (scene level: clear the "some view handed this Gaussian a gradient" bits the backward's wave triage reads; a word shared by
+  // two sets is cleared by both, all before any reduction kernel sets a bit)
+  if (touched_words && blockIdx.z == 0 && i < P && ((gi & 31) == 0 || i == 0)) touched_words[gi >> 5] = 0u;
   if (src.act != 0) {
     // rows i0 .. i0+255 of head_out are contiguous: coalesced copy into LDS, then row-strided reads (C odd: no conflicts)
     const int C = src.s_means;
@@ -243,7 +208,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
 #pragma unroll
       for (int k = 0; k < 6; ++k) c6[k] = src.cov[gi * 6 + k];
     } else {
-      cov3d_from_scale_rot(gin.s, mod, gin.q, c6);
+      exact::cov3d_from_scale_rot(gin.s, mod, gin.q, c6);
     }
     if (!src.colors) {
       const float* sh = lsrc.shs + li * (size_t)lsrc.s_shs;
@@ -275,9 +240,9 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
       const float p_w = 1.0f / (hom[3] + 0.0000001f);
       const float fx = (float)W / (2.f * tanx), fy = (float)H / (2.f * tany);
       Ewa e;
-      ewa_setup(e, p, cam, fx, fy, tanx, tany);
+      exact::ewa_setup(e, p, cam, fx, fy, tanx, tany);
       float abc[3];
-      cov2d(e, c6, abc);
+      exact::cov2d(e, c6, abc);
       const float det0 = abc[0] * abc[2] - abc[1] * abc[1];
       abc[0] += 0.3f; abc[2] += 0.3f;
       const float det = abc[0] * abc[2] - abc[1] * abc[1];
@@ -372,7 +337,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     U3DSpan span, int vpi, int M, int H, int W, float tanx, float tany, float mod, int flags, size_t NG, U3DSource src,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const double* acc, double* acc_reset,
-    U3DGradSink sink, const float* __restrict__ gscale) {
+    U3DGradSink sink, const float* __restrict__ gscale, const uint32_t* __restrict__ touched_words) {
 #pragma clang fp contract(fast)
   // gscale: device scalar dL/dloss of the fused step (autograd's grad_output) or null (= 1).  Every output of this kernel -- and the
   // column dot products quat_fixup finishes -- is linear in the accumulators, so scaling them as they are read IS the d_head * g
@@ -397,12 +362,25 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
   // (Only asked for at scene level, U3D_FLAG_INTERNAL_TRIAGE: at object level every Gaussian is live and the extra dependent
   // load phase costs this latency-bound kernel ~1 us.)
   bool lane_live = (flags & U3D_FLAG_INTERNAL_TRIAGE) == 0;
-  if (!lane_live) {
-    for (int vk = vslot; vk < (alive ? vpi : 0); vk += 4) {
-      const size_t g = pbase0 + (size_t)vk * P + i;
-      lane_live = lane_live || (radii[g] > 0 && (clamped[g] & U3D_TOUCHED_BIT) != 0u);
+  // scene level, fused mode: the block first clears ITS 64 rows of d(head output) with full-width stores (64 x C consecutive floats),
+  // then only the waves that own a touched Gaussian compute anything; a row-by-row zero fill from each idle wave ran at ~1 TB/s
+  const bool block_zero = !lane_live && src.act != 0;
+  if (block_zero) {
+    const int C = src.s_means, ib = blockIdx.x * (U3D_BLOCK / 4), rows = min(U3D_BLOCK / 4, P - ib);
+    if (rows > 0) {
+      float* o = sink.means + (gbase + ib) * C;
+      const int n = rows * C;
+      if ((reinterpret_cast<uintptr_t>(o) & 15u) == 0u) {
+        const int n4 = n >> 2;
+        for (int e = threadIdx.x; e < n4; e += U3D_BLOCK) reinterpret_cast<float4*>(o)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = (n4 << 2) + threadIdx.x; e < n; e += U3D_BLOCK) o[e] = 0.f;
+      } else {
+        for (int e = threadIdx.x; e < n; e += U3D_BLOCK) o[e] = 0.f;
+      }
     }
+    __syncthreads();   // (the rows a live wave writes below belong to this block)
   }
+  if (!lane_live) lane_live = alive && ((touched_words[gi >> 5] >> (uint32_t)(gi & 31)) & 1u) != 0u;   // one word per 32 Gaussians
   if (__ballot(lane_live) == 0ull) {
     if (sink.means2D) {
       for (int vk = vslot; vk < (alive ? vpi : 0); vk += 4) {
@@ -411,10 +389,12 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
       }
     }
     if (src.act != 0) {
-      // fused mode: the gradient rows of the wave's 16 Gaussians are 16 * C consecutive floats of d(head output)
-      const int C = src.s_means, iw = blockIdx.x * (U3D_BLOCK / 4) + (threadIdx.x >> 6) * 16, n = min(16, P - iw) * C;
-      float* o = sink.means + (gbase + iw) * C;
-      for (int e = threadIdx.x & 63; e < n; e += 64) o[e] = 0.f;
+      if (!block_zero) {
+        // fused mode: the gradient rows of the wave's 16 Gaussians are 16 * C consecutive floats of d(head output)
+        const int C = src.s_means, iw = blockIdx.x * (U3D_BLOCK / 4) + (threadIdx.x >> 6) * 16, n = min(16, P - iw) * C;
+        float* o = sink.means + (gbase + iw) * C;
+        for (int e = threadIdx.x & 63; e < n; e += 64) o[e] = 0.f;
+      }
     } else if (writer) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) sink.means[gi * src.s_means + k] = 0.f;
@@ -448,7 +428,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
 #pragma unroll
     for (int k = 0; k < 6; ++k) c6[k] = src.cov[gi * 6 + k];
   } else {
-    cov3d_from_scale_rot(s, mod, q, c6);
+    fast::cov3d_from_scale_rot(s, mod, q, c6);
   }
   const float op_in = gin.op;
   float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
@@ -460,11 +440,19 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
   for (int vk = vslot; vk < (alive ? vpi : 0); vk += 4) {
     const int view = item * vpi + vk;
     const size_t g = pbase0 + (size_t)vk * P + i;
+    // every load of this (view, Gaussian) is issued before anything is decided (this kernel is a chain of dependent memory round
+    // trips -- triage word, flags, accumulators, camera -- not arithmetic: the accumulators of an untouched pair are zero anyway)
     const uint32_t cbits = clamped[g];
-    const bool live = radii[g] > 0 && (cbits & U3D_TOUCHED_BIT) != 0u;   // visible AND handed a gradient by the reduction
+    const int32_t rad = radii[g];
+    double av[U3D_NACC];
+#pragma unroll
+    for (int k = 0; k < U3D_NACC; ++k) av[k] = acc[(size_t)k * NG + g];
+    Cam cam;
+    load_cam(cam, viewmatrix, projmatrix, campos, view);
+    const bool live = rad > 0 && (cbits & U3D_TOUCHED_BIT) != 0u;   // visible AND handed a gradient by the reduction
     float a[U3D_NACC];
 #pragma unroll
-    for (int k = 0; k < U3D_NACC; ++k) a[k] = live ? (float)acc[(size_t)k * NG + g] * gs : 0.f;
+    for (int k = 0; k < U3D_NACC; ++k) a[k] = live ? (float)av[k] * gs : 0.f;
     if (acc_reset && live) {   // single-pass step: hand the accumulators back zeroed (only touched pairs were ever written)
 #pragma unroll
       for (int k = 0; k < U3D_NACC; ++k) acc_reset[(size_t)k * NG + g] = 0.0;
@@ -479,12 +467,10 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
 #pragma unroll
     for (int k = 0; k < U3D_NACC; ++k) nz = nz || a[k] != 0.f;
     if (!nz) continue;
-    Cam cam;
-    load_cam(cam, viewmatrix, projmatrix, campos, view);
     Ewa e;
-    ewa_setup(e, p, cam, fx, fy, tanx, tany);
+    fast::ewa_setup(e, p, cam, fx, fy, tanx, tany);
     float abc[3];
-    cov2d(e, c6, abc);
+    fast::cov2d(e, c6, abc);
     float c_xx = abc[0], c_xy = abc[1], c_yy = abc[2];
     const float x0 = c_xx, y0 = c_yy, h_var = 0.3f;
     float d_inside_root = 0.f;
@@ -637,7 +623,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     const float Gs[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
                          0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
     float R[9], Mx[9], sv[3];
-    quat_to_R(q, R);
+    fast::quat_to_R(q, R);
 #pragma unroll
     for (int k = 0; k < 3; ++k) sv[k] = mod * s[k];
 #pragma unroll
@@ -799,7 +785,8 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
   hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, lds, s, u3d_span(d), d.views_per_item, vpt, d.image_height, \
                      d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, src, viewmatrix, projmatrix, campos, \
                      radii, b.depth, b.xy, b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered, acc_zero, NG,               \
-                     fuse_sort ? b.sorted_id : nullptr, b.sorted_rect, b.n_vis)
+                     fuse_sort ? b.sorted_id : nullptr, b.sorted_rect, b.n_vis, d.P > U3D_LDS_SORT_MAX ? b.sort_hist : nullptr, u3d_msd_bins(d.P), \
+                     u3d_uses_touched_words(d) ? b.touched_words : nullptr)
   switch (D) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;
@@ -819,7 +806,7 @@ void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 #define LAUNCH(DEG)                                                                                                    \
   hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, u3d_span(d), d.views_per_item, d.sh_coeffs, d.image_height, \
                      d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, flags, NG, src, viewmatrix, projmatrix,    \
-                     campos, radii, b.clamped, acc, acc_reset, sink, gscale)
+                     campos, radii, b.clamped, acc, acc_reset, sink, gscale, b.touched_words)
   switch (D) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;

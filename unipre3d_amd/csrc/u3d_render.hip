@@ -123,6 +123,8 @@ struct TileGeom {
   const uint32_t* sorted_id; const uint2* sorted_rect; const float2* xy; const float4* conic_op; const float4* rgbd;
   size_t vbase; int tx, ty;
   uint32_t* touched;   // the `clamped` words (U3D_TOUCHED_BIT), backward only
+  uint32_t* tw;        // per-Gaussian touched bitmap (scene level only, else null) and the first Gaussian of the view's set
+  size_t gbase;
 };
 
 // stage sorted entries [b*64, b*64+64) limited to `limit`; returns the hit ballot (compaction keeps the order).
@@ -440,7 +442,10 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
           const float v = moment_to_acc<float>(k, m, co.x, co.y, co.z, co.w, half_w, half_h);
           if (v != 0.f) { unsafeAtomicAdd(&acc[(size_t)k * NG + g], (double)v); nz = true; }
         }
-        if (nz) G.touched[g] |= U3D_TOUCHED_BIT;   // (every writer ORs the same bit into an otherwise constant word)
+        if (nz) {
+          G.touched[g] |= U3D_TOUCHED_BIT;   // (every writer ORs the same bit into an otherwise constant word)
+          if (G.tw) u3d_mark_touched(G.tw, G.gbase + (g - G.vbase));
+        }
       }
     } else {
       // position-indexed rows of block b: the LDS rows (raw moments) this tile can have touched, 40 B per lane, plain stores;
@@ -515,7 +520,7 @@ static_assert(TILE_WAVES == 1, "one wave = one workgroup = one tile");
   int Pv_;        /* Gaussians of this view's set; first (view, Gaussian) pair (uniform batch: view * P, no division) */ \
   size_t vb_;                                                                                            \
   u3d_view_span(span, view, Pv_, vb_);                                                                   \
-  const TileGeom G{sorted_id, sorted_rect, xy, conic_op, rgbd, vb_, tx, ty, touched}
+  const TileGeom G{sorted_id, sorted_rect, xy, conic_op, rgbd, vb_, tx, ty, touched, touched_words, touched_words ? u3d_view_gbase(span, view) : 0}
 
 // ---- forward (operator path): colour, inverse depth, and the state the backward kernel restarts from --------
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
@@ -525,6 +530,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
     float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last, U3DLoss loss) {
   uint32_t* const touched = nullptr;
+  uint32_t* const touched_words = nullptr;
   __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ float sD[TILE_WAVES][U3D_WAVE];
@@ -570,7 +576,8 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_dinvdepth, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_last, double* __restrict__ acc,
-    float* __restrict__ part, const float* __restrict__ out_color, uint32_t* __restrict__ touched, U3DLoss loss) {
+    float* __restrict__ part, const float* __restrict__ out_color, uint32_t* __restrict__ touched, uint32_t* __restrict__ touched_words,
+    U3DLoss loss) {
   __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ float sD[TILE_WAVES][HAS_INVD ? U3D_WAVE : 1];
@@ -643,7 +650,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis,
     const float2* __restrict__ xy, const float4* __restrict__ conic_op, const float4* __restrict__ rgbd,
     const float* __restrict__ bg, float* __restrict__ out_color, double* __restrict__ acc, float* __restrict__ part,
-    uint32_t* __restrict__ touched, U3DLoss loss) {
+    uint32_t* __restrict__ touched, uint32_t* __restrict__ touched_words, U3DLoss loss) {
   __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ __attribute__((aligned(8))) float sAcc[TILE_WAVES][U3D_WAVE][10];
@@ -707,7 +714,8 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(U3DSpan span
                                                                    const float4* __restrict__ conic_op,
                                                                    const float* __restrict__ part,
                                                                    const uint32_t* __restrict__ part_cnt,
-                                                                   double* __restrict__ acc, uint32_t* __restrict__ touched, int n_loss,
+                                                                   double* __restrict__ acc, uint32_t* __restrict__ touched,
+                                                                   uint32_t* __restrict__ touched_words, int n_loss,
                                                                    const float* __restrict__ loss_partial, float inv_count,
                                                                    float* __restrict__ loss_out) {
   __shared__ double s_sum[U3D_WAVE][10];
@@ -801,7 +809,10 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(U3DSpan span
         const float4 co = conic_op[g];
         const double outv = moment_to_acc<double>(k, m, co.x, co.y, co.z, co.w, half_w, half_h);
         if (outv != 0.0) unsafeAtomicAdd(&acc[(size_t)k * NG + g], outv);
-        if (k == 0) touched[g] |= U3D_TOUCHED_BIT;   // this (view, Gaussian) has a non-zero row
+        if (k == 0) {
+          touched[g] |= U3D_TOUCHED_BIT;   // this (view, Gaussian) has a non-zero row
+          if (touched_words) u3d_mark_touched(touched_words, u3d_view_gbase(span, view) + (g - vb));
+        }
       }
     }
   }
@@ -814,7 +825,8 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce1_kernel(U3DSpan spa
                                                                    const float4* __restrict__ conic_op,
                                                                    const float* __restrict__ part,
                                                                    const uint32_t* __restrict__ part_cnt,
-                                                                   double* __restrict__ acc, uint32_t* __restrict__ touched, int n_loss,
+                                                                   double* __restrict__ acc, uint32_t* __restrict__ touched,
+                                                                   uint32_t* __restrict__ touched_words, int n_loss,
                                                                    const float* __restrict__ loss_partial, float inv_count,
                                                                    float* __restrict__ loss_out) {
   __shared__ double s_sum[U3D_WAVE][10];
@@ -900,7 +912,10 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce1_kernel(U3DSpan spa
   const float4 co = conic_op[g];
   const double outv = moment_to_acc<double>(k, m, co.x, co.y, co.z, co.w, half_w, half_h);
   if (outv != 0.0) unsafeAtomicAdd(&acc[(size_t)k * NG + g], outv);
-  if (k == 0) touched[g] |= U3D_TOUCHED_BIT;   // this (view, Gaussian) has a non-zero row
+  if (k == 0) {
+    touched[g] |= U3D_TOUCHED_BIT;   // this (view, Gaussian) has a non-zero row
+    if (touched_words) u3d_mark_touched(touched_words, u3d_view_gbase(span, view) + (g - vb));
+  }
 }
 
 
@@ -960,19 +975,20 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
   const size_t NG = (size_t)d.views_per_item * u3d_total_P(d);
   if (ntiles == 0 || NG == 0) return;
   const TileGrid tg = tile_grid(d, tiles_x, T);
+  uint32_t* tw = u3d_uses_touched_words(d) ? b.touched_words : nullptr;
   if (u3d_part_blocks(d) == 1)
     hipLaunchKernelGGL(render_fb_wave_kernel<1>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height, d.image_width,
                        tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
-                       acc, part, b.clamped, loss);
+                       acc, part, b.clamped, tw, loss);
   else
     hipLaunchKernelGGL(render_fb_wave_kernel<U3D_PART_BLOCKS>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height,
                        d.image_width, tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg,
-                       out_color, acc, part, b.clamped, loss);
+                       out_color, acc, part, b.clamped, tw, loss);
   const int nsplit = bwd_reduce_split(T, d.n_items * d.views_per_item);
   auto* reduce_k = u3d_part_blocks(d) == 1 ? bwd_reduce1_kernel : bwd_reduce_kernel<U3D_PART_BLOCKS>;
   hipLaunchKernelGGL(reduce_k, dim3(d.n_items * d.views_per_item, nsplit + 1), dim3(REDUCE_THREADS), 0, s,
                      u3d_span(d), T, U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id, b.conic_op, part,
-                     reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, (int)ntiles, loss.partial,
+                     reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, tw, (int)ntiles, loss.partial,
                      loss.inv_count, loss_out);
 }
 
@@ -986,10 +1002,11 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   if (ntiles == 0 || NG == 0) return;
   const TileGrid tg = tile_grid(d, tiles_x, T);
   const bool invd = dL_dinvdepth && loss.kind == 0;
+  uint32_t* tw = u3d_uses_touched_words(d) ? b.touched_words : nullptr;
 #define LAUNCH(INVD, PBV)                                                                                                   \
   hipLaunchKernelGGL((render_bwd_wave_kernel<INVD, PBV>), tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height, \
                      d.image_width, tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg,    \
-                     dL_dcolor, dL_dinvdepth, b.final_T, b.n_contrib, b.tile_last, acc, part, out_color, b.clamped, loss)
+                     dL_dcolor, dL_dinvdepth, b.final_T, b.n_contrib, b.tile_last, acc, part, out_color, b.clamped, tw, loss)
   if (u3d_part_blocks(d) == 1) { if (invd) LAUNCH(true, 1); else LAUNCH(false, 1); }
   else { if (invd) LAUNCH(true, U3D_PART_BLOCKS); else LAUNCH(false, U3D_PART_BLOCKS); }
 #undef LAUNCH
@@ -997,6 +1014,6 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   auto* reduce_k = u3d_part_blocks(d) == 1 ? bwd_reduce1_kernel : bwd_reduce_kernel<U3D_PART_BLOCKS>;
   hipLaunchKernelGGL(reduce_k, dim3(d.n_items * d.views_per_item, nsplit), dim3(REDUCE_THREADS), 0, s,
                      u3d_span(d), T, invd ? U3D_NACC : U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id,
-                     b.conic_op, part, reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, 0, nullptr, 0.f,
+                     b.conic_op, part, reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, tw, 0, nullptr, 0.f,
                      nullptr);
 }

@@ -9,8 +9,8 @@
 //
 //  * P <= 256: fused into preprocess_fwd (bitonic network over 256 (depth bits << 32 | index) keys in LDS).
 //  * P <= 4096: one workgroup per view, 4-pass LSD radix sort entirely in LDS (64 KiB of the CU's 160 KiB), one launch.
-//  * larger P: one most-significant-digit partition into 512 depth buckets (histogram + stable scatter), then one workgroup per
-//    bucket sorts it in LDS and writes the sorted ids and tile rectangles: three launches (see below).
+//  * larger P: one most-significant-digit partition into 512 depth buckets (histogram + unordered scatter), then one workgroup per
+//    bucket RANKS its (key, index) pairs in LDS and writes the sorted ids and tile rectangles: three launches (see below).
 #include "u3d_common.h"
 
 namespace {
@@ -119,29 +119,42 @@ __global__ __launch_bounds__(NT) void depth_sort_block_radix_kernel(U3DSpan span
   }
 }
 
-// ---- large P: one most-significant-digit partition, then every bucket sorted by its own workgroup -------------------------
+// ---- large P: a coarse most-significant-digit partition, then every bucket sub-binned and ranked by its own workgroup --------
 // Key = depth bits - bits(0.2f): a visible Gaussian has depth > 0.2 (the near cull), so the difference is >= 1 and order-preserving.
-// Bucket = min(key >> 18, 511): 32 buckets per octave of depth up to 13107.2, everything beyond in the last one.
-//   msd_hist     per-block bucket histogram (culled Gaussians are dropped here: they are neither counted nor moved);
-//   msd_scatter  stable partition into bucket order (ballot multi-split ranking, per-block offsets from the histograms), bucket
-//                start table, n_vis;
-//   bucket_sort  one 256- or 512-thread workgroup per (view, bucket): LSD radix sort (6-bit digits) of the bucket's keys on their low 18 bits (the
-//                whole key in the last bucket), in LDS when the bucket fits (<= 1024 keys), through the global ping-pong buffers
-//                otherwise (an unusually dense or degenerate bucket: correct, slower); writes the sorted ids and rectangles.
-// Three launches instead of the nine of a four-pass LSD sort over all keys (each of which is latency-bound at these sizes).
-// Stable throughout and the initial order is index order, so depth ties resolve by ascending Gaussian index.
-constexpr uint32_t MSD_KEY_BASE = 0x3E4CCCCDu;   // bits of 0.2f
-constexpr int MSD_SHIFT = 18, MSD_BITS = 9, MSD_BINS = 1 << MSD_BITS;
-constexpr int BUCKET_LDS_CAP = 1024;
+// Bucket = min(key >> 18, 511): 32 buckets per octave of depth up to 13107.2, everything beyond in the last one (64 per octave, 1024
+// buckets, beyond 64 k Gaussians per view).
+// No step below is stable and none needs to be: the final position of a pair is its RANK by (key, index) inside its bucket, so
+// "ascending depth bits, ties by ascending Gaussian index" comes out whatever order the atomics produced (bit-identical runs).
+//   msd_hist     per-workgroup bucket histogram in LDS (culled pairs are neither counted nor moved); each non-empty (workgroup,
+//                bucket) count reserves its slice of the bucket with ONE global atomic on the view's totals (zeroed by
+//                preprocess_fwd) and keeps the slice offset -- ~170 atomics per 4096 keys, not one per key (a global atomic per
+//                key measured 5 x the whole old sort);
+//   msd_scatter  bucket starts = scan of the 512 totals (every workgroup redoes it), destination = start + slice offset + the
+//                key's arrival number inside the workgroup's slice (an LDS atomic): no column walk over per-workgroup tables, no
+//                ballot multi-split;
+//   bucket_sort  one workgroup per (view, bucket): the bucket's pairs go to 256 sub-bins of the next 8 key bits in LDS (LDS
+//                atomics), then every pair counts the smaller pairs of its own sub-bin (a dozen of them): four barriers instead
+//                of the ~30 of three LSD radix passes.  The last bucket (keys differ above bit 18), a bucket beyond the LDS
+//                capacity and a bucket with a sub-bin of more than 512 pairs (thousands of near-equal depths) take stable LSD
+//                radix passes over (index bits, then key bits) -- in LDS up to 1024 keys, through the global ping-pong buffers
+//                beyond: correct for any input, slower.
+// Round 2 (stable ballot multi-split scatter with a column walk, three 6-bit radix passes per bucket): C5 5.3 + 27.3 + 50.3 us,
+// C4 5.0 + 16.0 + 20.3 us.  Sorted positions at and beyond n_vis[view] are NOT written: nothing reads them (tile_stage stops there).
+constexpr uint32_t MSD_KEY_BASE = U3D_MSD_KEY_BASE;   // bits of 0.2f
+// SHIFT = 18: 512 buckets, 32 per octave (up to 64 k Gaussians per view); SHIFT = 17: 1024 buckets, 64 per octave (beyond: halves the
+// buckets, so that a 256-thread workgroup with 16 KB of LDS still holds one and all of them are resident at once)
+template <int SHIFT> struct Msd { static constexpr int BINS = 16 << (23 - SHIFT); static_assert(BINS <= U3D_MSD_BINS_MAX, "scratch is carved for this many"); };
+constexpr int SUB_BITS = 8, SUB_BINS = 1 << SUB_BITS;
+constexpr int SUB_MAX = 512;                          // largest sub-bin ranked by all-pairs comparison
+constexpr int BUCKET_LDS_CAP = 1024;                  // largest bucket the radix fallback sorts in LDS
 
-__device__ __forceinline__ uint32_t msd_key(int P, int idx, size_t base, const float* depth, const int32_t* radii) {
-  return radii[base + idx] > 0 ? __float_as_uint(depth[base + idx]) - MSD_KEY_BASE : 0xFFFFFFFFu;
-}
-__device__ __forceinline__ uint32_t msd_bucket(uint32_t k) { return min(k >> MSD_SHIFT, (uint32_t)(MSD_BINS - 1)); }
+template <int SHIFT> __device__ __forceinline__ uint32_t msd_bucket(uint32_t k) { return min(k >> SHIFT, (uint32_t)(Msd<SHIFT>::BINS - 1)); }
 
-template <int NT, int ITEMS>
-__global__ __launch_bounds__(NT) void msd_hist_kernel(U3DSpan span, int nblk, const float* __restrict__ depth, const int32_t* __restrict__ radii,
-                                                      uint32_t* __restrict__ hist) {
+template <int NT, int ITEMS, int SHIFT>
+__global__ __launch_bounds__(NT) void msd_hist_kernel(U3DSpan span, int nblk, const float* __restrict__ depth, uint32_t* __restrict__ total,
+                                                      uint32_t* __restrict__ slice_off) {
+  constexpr int MSD_BINS = Msd<SHIFT>::BINS;
+  static_assert(NT >= MSD_BINS, "one thread per bucket");
   __shared__ uint32_t h[MSD_BINS];
   const int view = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   int P;
@@ -153,103 +166,70 @@ __global__ __launch_bounds__(NT) void msd_hist_kernel(U3DSpan span, int nblk, co
   for (int r = 0; r < ITEMS; ++r) {
     const int idx = blk * (ITEMS * NT) + r * NT + tid;
     if (idx < P) {
-      const uint32_t k = msd_key(P, idx, base, depth, radii);
-      if (k != 0xFFFFFFFFu) atomicAdd(&h[msd_bucket(k)], 1u);
+      const float z = depth[base + idx];        // 0 for a culled pair, > 0.2 otherwise (preprocess_fwd)
+      if (z > 0.f) atomicAdd(&h[msd_bucket<SHIFT>(__float_as_uint(z) - MSD_KEY_BASE)], 1u);
     }
   }
   __syncthreads();
-  if (tid < MSD_BINS) hist[((size_t)view * nblk + blk) * MSD_BINS + tid] = h[tid];   // [view][block][bucket]: coalesced
+  if (tid < MSD_BINS) {
+    const uint32_t c = h[tid];
+    slice_off[((size_t)view * nblk + blk) * MSD_BINS + tid] = c ? atomicAdd(&total[(size_t)view * MSD_BINS + tid], c) : 0u;
+  }
 }
 
-template <int NT, int ITEMS>
-__global__ __launch_bounds__(NT) void msd_scatter_kernel(U3DSpan span, int nblk, const float* __restrict__ depth, const int32_t* __restrict__ radii,
+template <int NT, int ITEMS, int SHIFT>
+__global__ __launch_bounds__(NT) void msd_scatter_kernel(U3DSpan span, int nblk, const float* __restrict__ depth,
                                                          uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                         const uint32_t* __restrict__ hist, uint32_t* __restrict__ n_vis,
-                                                         uint32_t* __restrict__ bucket_off) {
-  constexpr int NW = NT / 64;
+                                                         const uint32_t* __restrict__ total, const uint32_t* __restrict__ slice_off,
+                                                         uint32_t* __restrict__ n_vis, uint32_t* __restrict__ bucket_off) {
+  constexpr int MSD_BINS = Msd<SHIFT>::BINS;
   static_assert(NT >= MSD_BINS, "one thread per bucket in the prologue");
-  extern __shared__ uint32_t s_dyn[];                                   // wave_cnt[2][NW][MSD_BINS], double-buffered per round:
-  uint32_t (*wave_cnt)[NW][MSD_BINS] = reinterpret_cast<uint32_t (*)[NW][MSD_BINS]>(s_dyn);   // counts, then prefixes over the waves
-  __shared__ uint32_t digit_base[MSD_BINS];
-  __shared__ uint32_t wave_tot[MSD_BINS / 64];
-  const int view = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
-  const int wave = tid >> 6;
+  __shared__ uint32_t s_base[MSD_BINS], s_cnt[MSD_BINS];
+  __shared__ uint32_t s_wave[MSD_BINS / 64];
+  const int view = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
   const uint32_t lane = u3d_lane_id();
   int P;
   size_t base;
   u3d_view_span(span, view, P, base);
-  for (int e = tid; e < 2 * NW * MSD_BINS; e += NT) (&wave_cnt[0][0][0])[e] = 0;
   {
-    // global offset of (bucket tid, this block) in bucket-major / block-minor order, from the per-block counts hist[view][b][bucket]
-    // (every block redoes this small scan: no separate scan launch; 8 loads in flight: the column walk is latency-bound)
-    uint32_t tot = 0, before = 0, inc = 0;
+    uint32_t tot = 0, inc = 0;
     if (tid < MSD_BINS) {
-      const uint32_t* col = hist + (size_t)view * nblk * MSD_BINS + tid;
-      int b = 0;
-      for (; b + 7 < nblk; b += 8) {
-        uint32_t c[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] = col[(size_t)(b + u) * MSD_BINS];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { tot += c[u]; before += b + u < blk ? c[u] : 0u; }
-      }
-      for (; b < nblk; ++b) { const uint32_t c0 = col[(size_t)b * MSD_BINS]; tot += c0; before += b < blk ? c0 : 0u; }
+      tot = total[(size_t)view * MSD_BINS + tid];
       inc = tot;   // inclusive scan of the bucket totals: shuffles inside each of the first waves, then the wave totals
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
         if ((int)lane >= o) inc += v;
       }
-      if (lane == 63) wave_tot[wave] = inc;
+      if (lane == 63) s_wave[wave] = inc;
+      s_cnt[tid] = 0;
     }
     __syncthreads();
     if (tid < MSD_BINS) {
       uint32_t off = 0;
-      for (int w = 0; w < wave; ++w) off += wave_tot[w];
+      for (int w = 0; w < wave; ++w) off += s_wave[w];
       const uint32_t start = off + inc - tot;
       if (blk == 0) {
         bucket_off[(size_t)view * (MSD_BINS + 1) + tid] = start;
         if (tid == MSD_BINS - 1) { bucket_off[(size_t)view * (MSD_BINS + 1) + MSD_BINS] = off + inc; n_vis[view] = off + inc; }
       }
-      digit_base[tid] = start + before;
+      s_base[tid] = start + slice_off[((size_t)view * nblk + blk) * MSD_BINS + tid];
     }
     __syncthreads();
   }
+#pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const int idx = blk * (ITEMS * NT) + r * NT + tid;
-    bool valid = idx < P;
-    uint32_t k = 0, digit = 0;
-    if (valid) {
-      k = msd_key(P, idx, base, depth, radii);
-      digit = msd_bucket(k);
-      valid = k != 0xFFFFFFFFu;
+    if (idx < P) {
+      const float z = depth[base + idx];
+      if (z > 0.f) {
+        const uint32_t k = __float_as_uint(z) - MSD_KEY_BASE;
+        const uint32_t bkt = msd_bucket<SHIFT>(k);
+        const uint32_t dst = s_base[bkt] + atomicAdd(&s_cnt[bkt], 1u);
+        keys_out[base + dst] = k;
+        vals_out[base + dst] = (uint32_t)idx;
+      }
     }
-    // lanes of this wave holding the same bucket (stable multi-split, one ballot per bit)
-    unsigned long long same = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < MSD_BITS; ++b) {
-      const bool bit = (digit >> b) & 1u;
-      const unsigned long long m = __ballot(bit && valid);
-      same &= bit ? m : ~m;
-    }
-    const uint32_t rank = __popcll(same & ((1ull << lane) - 1ull));
-    uint32_t (*cnt)[MSD_BINS] = wave_cnt[r & 1];
-    if (valid && rank == 0) cnt[wave][digit] = (uint32_t)__popcll(same);
-    __syncthreads();
-    if (tid < MSD_BINS) {   // counts -> destination of each wave's first key of this bucket; digit_base moves past the round
-      uint32_t run = digit_base[tid];
-#pragma unroll
-      for (int w = 0; w < NW; ++w) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = run; run += c; }
-      digit_base[tid] = run;
-    }
-    __syncthreads();
-    if (valid) {
-      const uint32_t dst = cnt[wave][digit] + rank;
-      keys_out[base + dst] = k;
-      vals_out[base + dst] = (uint32_t)idx;
-    }
-    for (int e = tid; e < NW * MSD_BINS; e += NT) (&wave_cnt[(r + 1) & 1][0][0])[e] = 0;   // the other buffer, for the next round
-    __syncthreads();
   }
 }
 
@@ -314,56 +294,128 @@ __device__ __forceinline__ void wg_radix_pass(const uint32_t* kin, const uint32_
   }
 }
 
-template <int BUCKET_NT>   // 256 threads per bucket up to 64 k Gaussians per view, 512 beyond (denser buckets: C5 sort 97 -> 85 us, C4 49 -> 52)
-__global__ __launch_bounds__(BUCKET_NT) void bucket_sort_kernel(U3DSpan span, int lds_cap, uint32_t* __restrict__ keys0, uint32_t* __restrict__ vals0,
-                                                                uint32_t* __restrict__ keys1, uint32_t* __restrict__ vals1,
-                                                                const uint32_t* __restrict__ bucket_off, const uint2* __restrict__ rect,
-                                                                uint32_t* __restrict__ sorted_id, uint2* __restrict__ sorted_rect) {
-  constexpr int NT = BUCKET_NT, NW = NT / 64;
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_data[];   // keys[2][cap], vals[2][cap]
-  constexpr int BITS = 6;
+// (key, index) order as one 64-bit compare
+__device__ __forceinline__ unsigned long long pair64(uint32_t k, uint32_t v) { return ((unsigned long long)k << 32) | v; }
+
+template <int NT, int ITEMS, int SHIFT>   // 256 x 8 = 2048 pairs in LDS
+__global__ __launch_bounds__(NT) void bucket_sort_kernel(U3DSpan span, uint32_t* __restrict__ keys0, uint32_t* __restrict__ vals0,
+                                                         uint32_t* __restrict__ keys1, uint32_t* __restrict__ vals1,
+                                                         const uint32_t* __restrict__ bucket_off, const uint2* __restrict__ rect,
+                                                         uint32_t* __restrict__ sorted_id, uint2* __restrict__ sorted_rect) {
+  constexpr int BITS = 6, CAP = NT * ITEMS, MSD_BINS = Msd<SHIFT>::BINS, MSD_SHIFT = SHIFT, SUB_SHIFT = SHIFT - SUB_BITS;
+  static_assert(NT >= SUB_BINS && 2 * CAP >= 4 * BUCKET_LDS_CAP, "sub-bin scan by one thread each; the radix fallback reuses the pair array");
+  __shared__ __attribute__((aligned(16))) unsigned long long s_pair[CAP];     // 16 / 32 KB
+  __shared__ uint32_t s_sub[SUB_BINS + 1];
+  __shared__ uint32_t s_wave[SUB_BINS / 64];
+  __shared__ uint32_t s_max;
   __shared__ uint32_t digit_base[1 << BITS];
-  __shared__ uint32_t wave_cnt[2][NW][1 << BITS];
-  const int view = blockIdx.y, bucket = blockIdx.x, tid = threadIdx.x;
+  __shared__ uint32_t wave_cnt[2][NT / 64][1 << BITS];
+  const int view = blockIdx.y, bucket = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+  const uint32_t lane = u3d_lane_id();
   int P;
   size_t base;
   u3d_view_span(span, view, P, base);
   const uint32_t start = bucket_off[(size_t)view * (MSD_BINS + 1) + bucket], end = bucket_off[(size_t)view * (MSD_BINS + 1) + bucket + 1];
   const int n = (int)(end - start);
-  if (n == 0) {
-    // (positions past the visible keys read id 0 / empty rectangle: the last bucket's workgroup fills them)
-  } else if (n == 1) {
+  if (n == 0) return;
+  if (n == 1) {
     if (tid == 0) { const uint32_t v = vals0[base + start]; sorted_id[base + start] = v; sorted_rect[base + start] = rect[base + v]; }
-  } else {
-    // bits that can differ inside a bucket: the low 18 (three 6-bit digits), the whole key in the last bucket (six)
-    const int passes = bucket == MSD_BINS - 1 ? 6 : 3;
-    const uint32_t* kf;
-    const uint32_t* vf;
-    if (n <= lds_cap) {
-      uint32_t* lk[2] = {s_data, s_data + lds_cap};
-      uint32_t* lv[2] = {s_data + 2 * lds_cap, s_data + 3 * lds_cap};
-      for (int i = tid; i < n; i += NT) { lk[0][i] = keys0[base + start + i]; lv[0][i] = vals0[base + start + i]; }
-      __syncthreads();
-      for (int p = 0; p < passes; ++p)
-        wg_radix_pass<NT, BITS>(lk[p & 1], lv[p & 1], lk[(p + 1) & 1], lv[(p + 1) & 1], n, BITS * p, digit_base, wave_cnt);
-      kf = lk[passes & 1]; vf = lv[passes & 1];
-    } else {
-      uint32_t* gk[2] = {keys0 + base + start, keys1 + base + start};
-      uint32_t* gv[2] = {vals0 + base + start, vals1 + base + start};
-      for (int p = 0; p < passes; ++p)
-        wg_radix_pass<NT, BITS>(gk[p & 1], gv[p & 1], gk[(p + 1) & 1], gv[(p + 1) & 1], n, BITS * p, digit_base, wave_cnt);
-      kf = gk[passes & 1]; vf = gv[passes & 1];
-    }
-    (void)kf;
-    for (int i = tid; i < n; i += NT) {
-      const uint32_t v = vf[i];
-      sorted_id[base + start + i] = v;
-      sorted_rect[base + start + i] = rect[base + v];
-    }
+    return;
   }
-  if (bucket == MSD_BINS - 1) {
-    const uint32_t nv = bucket_off[(size_t)view * (MSD_BINS + 1) + MSD_BINS];
-    for (int i = (int)nv + tid; i < P; i += NT) { sorted_id[base + i] = 0u; sorted_rect[base + i] = make_uint2(0u, 0u); }
+  bool fallback = n > CAP || bucket == MSD_BINS - 1;
+  if (!fallback) {
+    // sub-bin = the next 8 key bits below the bucket's; arrival number inside the sub-bin from an LDS atomic
+    uint32_t k[ITEMS], v[ITEMS], slot[ITEMS];
+    if (tid < SUB_BINS) s_sub[tid] = 0;
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+      const int i = r * NT + tid;
+      if (i < n) {
+        k[r] = keys0[base + start + i];
+        v[r] = vals0[base + start + i];
+        slot[r] = atomicAdd(&s_sub[(k[r] >> SUB_SHIFT) & (SUB_BINS - 1)], 1u);
+      }
+    }
+    __syncthreads();
+    {   // exclusive scan of the 256 sub-bin counts (first four waves) + the largest sub-bin
+      uint32_t tot = 0, inc = 0;
+      if (tid < SUB_BINS) {
+        tot = s_sub[tid];
+        inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
+          if ((int)lane >= o) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        if (tot > (uint32_t)SUB_MAX) atomicMax(&s_max, tot);
+      }
+      __syncthreads();
+      if (tid < SUB_BINS) {
+        uint32_t off = 0;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        s_sub[tid] = off + inc - tot;
+        if (tid == SUB_BINS - 1) s_sub[SUB_BINS] = off + inc;
+      }
+      __syncthreads();
+    }
+    fallback = s_max != 0u;     // (workgroup-uniform) a sub-bin too large to rank by comparison: near-equal depths by the thousand
+    if (!fallback) {
+#pragma unroll
+      for (int r = 0; r < ITEMS; ++r) {
+        const int i = r * NT + tid;
+        if (i < n) s_pair[s_sub[(k[r] >> SUB_SHIFT) & (SUB_BINS - 1)] + slot[r]] = pair64(k[r], v[r]);
+      }
+      __syncthreads();
+      for (int p = tid; p < n; p += NT) {
+        const unsigned long long mine = s_pair[p];
+        const uint32_t sub = ((uint32_t)(mine >> 32) >> SUB_SHIFT) & (SUB_BINS - 1);
+        const uint32_t s0 = s_sub[sub], s1 = s_sub[sub + 1];
+        uint32_t rank = s0;
+        for (uint32_t j = s0; j < s1; ++j) rank += s_pair[j] < mine ? 1u : 0u;
+        const uint32_t id = (uint32_t)mine;
+        sorted_id[base + start + rank] = id;
+        sorted_rect[base + start + rank] = rect[base + id];
+      }
+      return;
+    }
+    __syncthreads();
+  }
+  // ---- fallback: stable LSD radix passes, first over the index bits, then over the key bits that can differ inside the bucket ----
+  {
+    uint32_t* const s_data = reinterpret_cast<uint32_t*>(s_pair);
+    int idx_bits = 1;
+    while ((1 << idx_bits) < P) ++idx_bits;
+    const int idx_passes = (idx_bits + BITS - 1) / BITS;
+    const int key_passes = bucket == MSD_BINS - 1 ? (32 + BITS - 1) / BITS : (MSD_SHIFT + BITS - 1) / BITS;
+    const int passes = idx_passes + key_passes;
+    // ping-pong buffers: LDS up to BUCKET_LDS_CAP keys, the global key / value arrays beyond (pointers formed by arithmetic: an
+    // array of LDS addresses would be a constant initialiser the backend cannot express)
+    const bool in_lds = n <= BUCKET_LDS_CAP;
+    uint32_t* const k0 = in_lds ? s_data : keys0 + base + start;
+    uint32_t* const k1 = in_lds ? s_data + BUCKET_LDS_CAP : keys1 + base + start;
+    uint32_t* const v0 = in_lds ? s_data + 2 * BUCKET_LDS_CAP : vals0 + base + start;
+    uint32_t* const v1 = in_lds ? s_data + 3 * BUCKET_LDS_CAP : vals1 + base + start;
+    if (in_lds) {
+      for (int i = tid; i < n; i += NT) { k0[i] = keys0[base + start + i]; v0[i] = vals0[base + start + i]; }
+      __syncthreads();
+    }
+    for (int p = 0; p < passes; ++p) {
+      uint32_t* ki = (p & 1) ? k1 : k0; uint32_t* ko = (p & 1) ? k0 : k1;
+      uint32_t* vi = (p & 1) ? v1 : v0; uint32_t* vo = (p & 1) ? v0 : v1;
+      if (p < idx_passes)   // sort by an index digit: key and payload swap roles
+        wg_radix_pass<NT, BITS>(vi, ki, vo, ko, n, BITS * p, digit_base, wave_cnt);
+      else
+        wg_radix_pass<NT, BITS>(ki, vi, ko, vo, n, BITS * (p - idx_passes), digit_base, wave_cnt);
+    }
+    const uint32_t* vf = (passes & 1) ? v1 : v0;
+    for (int i = tid; i < n; i += NT) {
+      const uint32_t id = vf[i];
+      sorted_id[base + start + i] = id;
+      sorted_rect[base + start + i] = rect[base + id];
+    }
   }
 }
 
@@ -391,36 +443,20 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
     }
     return;
   }
+  // (the views' bucket totals b.sort_hist[NV][bins] were zeroed by preprocess_fwd)
   const int tile = u3d_radix_tile(d.P);
   const int nblk = (d.P + tile - 1) / tile;
-  // LDS per bucket workgroup decides how many buckets a CU sorts at once against how many take the global route: 1024 keys measured
-  // best up to 64 k Gaussians per view (C4), 4096 beyond (C5: denser buckets)
-  static const int lds_cap_env = getenv("U3D_BUCKET_LDS_CAP") ? atoi(getenv("U3D_BUCKET_LDS_CAP")) : 0;   // (tests force the global route)
-  const int lds_cap = lds_cap_env ? lds_cap_env : (d.P <= 65536 ? BUCKET_LDS_CAP : 4096);
-#define LAUNCH(NT, IT)                                                                                                       \
-  do {                                                                                                                       \
-    constexpr size_t lds = (size_t)2 * (NT / 64) * MSD_BINS * sizeof(uint32_t);                                              \
-    static bool attr = false;                                                                                                \
-    if (!attr) {                                                                                                             \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msd_scatter_kernel<NT, IT>),                                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sort_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                4 * 4096 * (int)sizeof(uint32_t));                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sort_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                4 * 4096 * (int)sizeof(uint32_t));                                                          \
-      attr = true;                                                                                                           \
-    }                                                                                                                        \
-    hipLaunchKernelGGL((msd_hist_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), 0, s, u3d_span(d), nblk, b.depth, radii, b.sort_hist);   \
-    hipLaunchKernelGGL((msd_scatter_kernel<NT, IT>), dim3(nblk, NV), dim3(NT), lds, s, u3d_span(d), nblk, b.depth, radii,            \
-                       b.sort_keys[0], b.sort_vals[0], b.sort_hist, b.n_vis, b.sort_over);                                   \
+  const int bins = u3d_msd_bins(d.P);
+  uint32_t* total = b.sort_hist;
+  uint32_t* slice_off = b.sort_hist + (size_t)NV * bins;
+#define LAUNCH(NT, IT, SH)                                                                                                                    \
+  do {                                                                                                                                        \
+    hipLaunchKernelGGL((msd_hist_kernel<NT, IT, SH>), dim3(nblk, NV), dim3(NT), 0, s, u3d_span(d), nblk, b.depth, total, slice_off);          \
+    hipLaunchKernelGGL((msd_scatter_kernel<NT, IT, SH>), dim3(nblk, NV), dim3(NT), 0, s, u3d_span(d), nblk, b.depth, b.sort_keys[0],          \
+                       b.sort_vals[0], total, slice_off, b.n_vis, b.sort_over);                                                               \
+    hipLaunchKernelGGL((bucket_sort_kernel<256, 8, SH>), dim3(bins, NV), dim3(256), 0, s, u3d_span(d), b.sort_keys[0], b.sort_vals[0],        \
+                       b.sort_keys[1], b.sort_vals[1], b.sort_over, b.rect, b.sorted_id, b.sorted_rect);                                      \
   } while (0)
-  if (d.P <= 65536) LAUNCH(U3D_RADIX_NT_SMALL, U3D_RADIX_IT_SMALL); else LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE);
+  if (d.P <= 65536) LAUNCH(U3D_RADIX_NT_SMALL, U3D_RADIX_IT_SMALL, 18); else LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE, 17);
 #undef LAUNCH
-  const int cap = lds_cap < 1 ? 1 : (lds_cap > 4096 ? 4096 : lds_cap);
-  if (d.P <= 65536)
-    hipLaunchKernelGGL(bucket_sort_kernel<256>, dim3(MSD_BINS, NV), dim3(256), (size_t)4 * cap * sizeof(uint32_t), s, u3d_span(d), cap, b.sort_keys[0],
-                       b.sort_vals[0], b.sort_keys[1], b.sort_vals[1], b.sort_over, b.rect, b.sorted_id, b.sorted_rect);
-  else
-    hipLaunchKernelGGL(bucket_sort_kernel<512>, dim3(MSD_BINS, NV), dim3(512), (size_t)4 * cap * sizeof(uint32_t), s, u3d_span(d), cap, b.sort_keys[0],
-                       b.sort_vals[0], b.sort_keys[1], b.sort_vals[1], b.sort_over, b.rect, b.sorted_id, b.sorted_rect);
 }
