@@ -54,7 +54,7 @@ def algorithmic_bytes(kind: str, P: int, R: float, T: int, HW: int) -> float:
     }[kind]
 
 
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 # measured instruction-class issue costs on gfx950, cycles per wave64 instruction per SIMD (profiles/r01/valu_instruction_classes.txt,
 # tools/ub/ops.hip under rocprofv3 --pmc): FMA / MUL / ADD / MOV 2.13, compare / min / select / DPP 4.08, exp / rcp 8.1; a scalar
 # instruction costs the SIMD's issue port about 1.7 (profiles/r01/ub_mixed_streams.txt: fma + s_and = 1.8 x an fma alone)

@@ -490,7 +490,11 @@ __device__ __forceinline__ void store4(float* __restrict__ p, bool vec, const bo
 // (6 waves per SIMD).  For the single-pass kernel, pinning 8 waves per SIMD (64 VGPRs) spills a handful of values around the rarely
 // taken variant and measured 3 % faster than the unpinned build, 4.5 % faster than the single-variant kernel; the two-pass kernels
 // measured slower pinned (forward 97 against 87 us at C2) and are left to the allocator.
+#ifdef U3D_NO_OCC_PIN   /* tools/pmc_spill_probe.sh: the unpinned build, to attribute the scratch-spill share of the kernel's HBM writes */
+#define U3D_FULL_OCCUPANCY
+#else
 #define U3D_FULL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
 // Grid = (T tiles of a view, views [, view slabs of 65535]): the view index comes from the block id, the tile row from a host-made
 // magic multiplier (`tile_magic`, 0 = divide), so the prologue has no integer division.  Workgroups are dispatched to the XCDs
 // round-robin in linear order x + T * view, which is what u3d_xcd_chunk_in_view assumes.
