@@ -139,6 +139,28 @@ def test_large_P_sort_dense_depth_bucket(oracle_mod, n_dense, spread):
         assert near(gg[k].reshape(go[k].shape), go[k], go64[k]), k
 
 
+@pytest.mark.parametrize("n_tied", [100, 700])
+def test_block_sort_clustered_depths(oracle_mod, n_tied):
+    """256 < P <= 4096: one workgroup per view ranks the pairs inside 1024 linear depth bins (six barriers); a bin with more than
+    256 pairs -- here 700 Gaussians at EXACTLY the same depth, which must come out in index order -- sends the view to the
+    four-pass LDS radix sort instead.  100 ties stay on the rank path."""
+    H, W = 64, 80
+    sc = scene(2000, H, W, seed=21, level="object", compact=True, deg=1)
+    V = sc["viewmatrix"].double()
+    fwd = V[:3, 2]
+    z = torch.cat([sc["means3D"].double(), torch.ones(2000, 1, dtype=torch.float64)], 1) @ V[:, 2]
+    idx = torch.arange(300, 300 + n_tied)
+    sc["means3D"][idx] += ((1.9 - z[idx])[:, None] * fwd[None, :]).float()
+    sc["opacities"][idx] = torch.linspace(0.05, 0.6, n_tied)[:, None]
+    dcol, dinv = cotangents(H, W)
+    color, invd, radii, gg = _run_gpu(sc, dcol, dinv)
+    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
+    assert np.array_equal(radii, r.radii) and near(color, r.color, r64.color)
+    go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
+    for k in DIFF_KEYS:
+        assert near(gg[k].reshape(go[k].shape), go[k], go64[k]), k
+
+
 def test_depth_ties_small_P(oracle_mod):
     sc = scene(200, 64, 96, seed=4, compact=True)
     sc["means3D"][10:40] = sc["means3D"][10]

@@ -231,6 +231,8 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
                                const float* projmatrix, const float* campos, int32_t* radii, double* acc_zero, hipStream_t s);
 // (preprocess_bwd triages by b.touched_words when d.P > U3D_LDS_SORT_MAX; the reduction kernels set the bits in that case)
 static inline bool u3d_uses_touched_words(const u3d_raster_desc& d) { return d.P > U3D_LDS_SORT_MAX; }
+// large-P sort: the tile kernels read a sorted entry's rectangle through sorted_id (b.rect) instead of a sorted copy (b.sorted_rect)
+static inline int u3d_rect_indirect(const u3d_raster_desc& d) { return d.P > U3D_LDS_SORT_MAX ? 1 : 0; }
 void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, const int32_t* radii, const double* acc,
                                const U3DGradSink& sink, hipStream_t s, double* acc_reset = nullptr, const float* gscale = nullptr);

@@ -122,6 +122,8 @@ struct TileLds {   // wave-private; 2560 B of staged entries + 2560 B of gradien
 struct TileGeom {
   const uint32_t* sorted_id; const uint2* sorted_rect; const float2* xy; const float4* conic_op; const float4* rgbd;
   size_t vbase; int tx, ty;
+  int rect_indirect;   // scene level: `sorted_rect` is the per-pair rectangle array, read through sorted_id (the depth sort of 10^5
+                       // pairs per view no longer gathers and rewrites 12 bytes per pair for the few dozen positions a tile reads)
   uint32_t* touched;   // the `clamped` words (U3D_TOUCHED_BIT), backward only
   uint32_t* tw;        // per-Gaussian touched bitmap (scene level only, else null) and the first Gaussian of the view's set
   size_t gbase;
@@ -141,7 +143,7 @@ template <bool DEPTH>
 __device__ __forceinline__ lanemask_t tile_stage(const TileLds& L, const TileGeom& G, int lane, int b, uint32_t limit, bool& plain) {
   const uint32_t s = (uint32_t)b * U3D_WAVE + (uint32_t)lane;
   bool hit = false, ok = true;
-  if (s < limit) hit = rect_hits(G.sorted_rect[G.vbase + s], G.tx, G.ty);
+  if (s < limit) hit = rect_hits(G.sorted_rect[G.vbase + (G.rect_indirect ? G.sorted_id[G.vbase + s] : s)], G.tx, G.ty);
   const lanemask_t bal = __ballot(hit);
   if (hit) {
     const uint32_t o = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
@@ -524,12 +526,12 @@ static_assert(TILE_WAVES == 1, "one wave = one workgroup = one tile");
   int Pv_;        /* Gaussians of this view's set; first (view, Gaussian) pair (uniform batch: view * P, no division) */ \
   size_t vb_;                                                                                            \
   u3d_view_span(span, view, Pv_, vb_);                                                                   \
-  const TileGeom G{sorted_id, sorted_rect, xy, conic_op, rgbd, vb_, tx, ty, touched, touched_words, touched_words ? u3d_view_gbase(span, view) : 0}
+  const TileGeom G{sorted_id, sorted_rect, xy, conic_op, rgbd, vb_, tx, ty, rect_indirect, touched, touched_words, touched_words ? u3d_view_gbase(span, view) : 0}
 
 // ---- forward (operator path): colour, inverse depth, and the state the backward kernel restarts from --------
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
     U3DSpan span, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, const uint32_t* __restrict__ sorted_id,
-    const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis, const float2* __restrict__ xy,
+    const uint2* __restrict__ sorted_rect, int rect_indirect, const uint32_t* __restrict__ n_vis, const float2* __restrict__ xy,
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last, U3DLoss loss) {
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
 template <bool HAS_INVD, int PB>
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
     U3DSpan span, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, size_t NG,
-    const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const float2* __restrict__ xy,
+    const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, int rect_indirect, const float2* __restrict__ xy,
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_dinvdepth, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_last, double* __restrict__ acc,
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
 template <int PB>
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void render_fb_wave_kernel(
     U3DSpan span, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, size_t NG,
-    const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, const uint32_t* __restrict__ n_vis,
+    const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, int rect_indirect, const uint32_t* __restrict__ n_vis,
     const float2* __restrict__ xy, const float4* __restrict__ conic_op, const float4* __restrict__ rgbd,
     const float* __restrict__ bg, float* __restrict__ out_color, double* __restrict__ acc, float* __restrict__ part,
     uint32_t* __restrict__ touched, uint32_t* __restrict__ touched_words, U3DLoss loss) {
@@ -967,7 +969,7 @@ void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   if (ntiles == 0) return;
   const TileGrid tg = tile_grid(d, tiles_x, T);
   hipLaunchKernelGGL(render_fwd_wave_kernel, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height, d.image_width,
-                     tiles_x, T, ntiles, tg.magic, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
+                     tiles_x, T, ntiles, tg.magic, b.sorted_id, u3d_rect_indirect(d) ? b.rect : b.sorted_rect, u3d_rect_indirect(d), b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
                      out_invdepth, b.final_T, b.n_contrib, b.tile_last, loss);
 }
 
@@ -982,11 +984,11 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
   uint32_t* tw = u3d_uses_touched_words(d) ? b.touched_words : nullptr;
   if (u3d_part_blocks(d) == 1)
     hipLaunchKernelGGL(render_fb_wave_kernel<1>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height, d.image_width,
-                       tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
+                       tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, u3d_rect_indirect(d) ? b.rect : b.sorted_rect, u3d_rect_indirect(d), b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
                        acc, part, b.clamped, tw, loss);
   else
     hipLaunchKernelGGL(render_fb_wave_kernel<U3D_PART_BLOCKS>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height,
-                       d.image_width, tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, b.sorted_rect, b.n_vis, b.xy, b.conic_op, b.rgbd, bg,
+                       d.image_width, tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, u3d_rect_indirect(d) ? b.rect : b.sorted_rect, u3d_rect_indirect(d), b.n_vis, b.xy, b.conic_op, b.rgbd, bg,
                        out_color, acc, part, b.clamped, tw, loss);
   const int nsplit = bwd_reduce_split(T, d.n_items * d.views_per_item);
   auto* reduce_k = u3d_part_blocks(d) == 1 ? bwd_reduce1_kernel : bwd_reduce_kernel<U3D_PART_BLOCKS>;
@@ -1009,7 +1011,7 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   uint32_t* tw = u3d_uses_touched_words(d) ? b.touched_words : nullptr;
 #define LAUNCH(INVD, PBV)                                                                                                   \
   hipLaunchKernelGGL((render_bwd_wave_kernel<INVD, PBV>), tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height, \
-                     d.image_width, tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, b.sorted_rect, b.xy, b.conic_op, b.rgbd, bg,    \
+                     d.image_width, tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, u3d_rect_indirect(d) ? b.rect : b.sorted_rect, u3d_rect_indirect(d), b.xy, b.conic_op, b.rgbd, bg,    \
                      dL_dcolor, dL_dinvdepth, b.final_T, b.n_contrib, b.tile_last, acc, part, out_color, b.clamped, tw, loss)
   if (u3d_part_blocks(d) == 1) { if (invd) LAUNCH(true, 1); else LAUNCH(false, 1); }
   else { if (invd) LAUNCH(true, U3D_PART_BLOCKS); else LAUNCH(false, U3D_PART_BLOCKS); }

@@ -22,14 +22,11 @@ namespace {
 // become destinations through one prefix over the waves.  1024 threads (a lone 4-wave workgroup per CU cannot hide its own
 // LDS and barrier latency: 34 us); measured at C3 (P = 2048, 64 views): 21 us against 32 us for a 66-stage bitonic network.
 template <int NT>
-__global__ __launch_bounds__(NT) void depth_sort_block_radix_kernel(U3DSpan span, int N, const float* __restrict__ depth,
-                                                                    const int32_t* __restrict__ radii,
-                                                                    const uint2* __restrict__ rect,
-                                                                    uint32_t* __restrict__ sorted_id,
-                                                                    uint2* __restrict__ sorted_rect,
-                                                                    uint32_t* __restrict__ n_vis) {
+__device__ __forceinline__ void block_radix_sort(U3DSpan span, int N, const float* __restrict__ depth, const int32_t* __restrict__ radii,
+                                                 const uint2* __restrict__ rect, uint32_t* __restrict__ sorted_id,
+                                                 uint2* __restrict__ sorted_rect, uint32_t* __restrict__ n_vis, uint32_t* lds) {
   constexpr int NW = NT / 64;
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // keys[2][N], vals[2][N]
+  // lds: keys[2][N], vals[2][N]
   __shared__ uint32_t digit_base[256];
   __shared__ uint32_t wave_cnt[2][NW][256];   // double-buffered per round: counts, then exclusive prefixes over the waves
   __shared__ uint32_t wave_tot[4];
@@ -117,6 +114,109 @@ __global__ __launch_bounds__(NT) void depth_sort_block_radix_kernel(U3DSpan span
     sorted_id[base + i] = id;
     sorted_rect[base + i] = vis ? rect[base + id] : make_uint2(0u, 0u);
   }
+}
+
+// ---- 256 < P <= 4096, first attempt: rank inside linear depth bins (round 3) ----------------------------------------------------
+// The four radix passes above cost ~50 workgroup barriers (C3: 19 us for 2048 keys).  Object-level depths sit within an octave or
+// two, so 1024 bins LINEAR in the key (depth bits) between the view's smallest and largest visible key hold a handful of keys each:
+// bin by an LDS atomic, scan, scatter the (key, index) pairs to LDS, and every pair counts the smaller pairs of its own bin -- the
+// rank gives "ascending depth bits, ties by ascending index" whatever order the atomics produced (six barriers).  Returns false
+// (workgroup-uniform, nothing written) when some bin holds more than 256 pairs -- clustered depths -- and the radix sort runs.
+template <int NT>
+__device__ __forceinline__ bool block_rank_sort(U3DSpan span, int N, const float* __restrict__ depth, const int32_t* __restrict__ radii,
+                                                const uint2* __restrict__ rect, uint32_t* __restrict__ sorted_id,
+                                                uint2* __restrict__ sorted_rect, uint32_t* __restrict__ n_vis, uint32_t* lds) {
+  constexpr int BINS = 1024, ITEMS = U3D_LDS_SORT_MAX / NT, BIN_MAX = 256;
+  static_assert(NT == BINS, "one thread per bin in the scan");
+  unsigned long long* pairs = reinterpret_cast<unsigned long long*>(lds);   // [N] (the radix sort's buffers, 16 N bytes, hold them)
+  __shared__ uint32_t s_bin[BINS + 1];
+  __shared__ uint32_t s_wv[NT / 64];
+  __shared__ uint32_t s_min, s_max, s_big;
+  const int view = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+  const uint32_t lane = u3d_lane_id();
+  int P;
+  size_t base;
+  u3d_view_span(span, view, P, base);
+  uint32_t k[ITEMS], slot[ITEMS];
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const int i = r * NT + tid;
+    k[r] = (i < P && radii[base + i] > 0) ? __float_as_uint(depth[base + i]) : 0xFFFFFFFFu;
+    if (k[r] != 0xFFFFFFFFu) { lo = min(lo, k[r]); hi = max(hi, k[r]); }
+  }
+  s_bin[tid] = 0;
+  if (tid == 0) { s_min = 0xFFFFFFFFu; s_max = 0u; s_big = 0u; s_bin[BINS] = 0; }
+  __syncthreads();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
+  if (lane == 0 && lo != 0xFFFFFFFFu) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+  __syncthreads();
+  const uint32_t kmin = s_min, kmax = s_max;
+  if (kmin == 0xFFFFFFFFu) {   // nothing visible
+    if (tid == 0) n_vis[view] = 0;
+    for (int i = tid; i < P; i += NT) { sorted_id[base + i] = 0u; sorted_rect[base + i] = make_uint2(0u, 0u); }
+    return true;
+  }
+  const uint32_t range = kmax - kmin;
+  const int shift = range < (uint32_t)BINS ? 0 : (32 - __clz((int)range)) - 10;   // (range >> shift) < 1024
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r)
+    if (k[r] != 0xFFFFFFFFu) slot[r] = atomicAdd(&s_bin[(k[r] - kmin) >> shift], 1u);
+  __syncthreads();
+  {   // exclusive scan of the 1024 bin counts (one per thread) + the oversize test
+    const uint32_t tot = s_bin[tid];
+    uint32_t inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
+      if ((int)lane >= o) inc += t;
+    }
+    if (lane == 63) s_wv[wave] = inc;
+    if (tot > (uint32_t)BIN_MAX) s_big = 1u;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += s_wv[w];
+    s_bin[tid] = off + inc - tot;
+    if (tid == NT - 1) s_bin[BINS] = off + inc;
+    __syncthreads();
+  }
+  if (s_big != 0u) { __syncthreads(); return false; }
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r)
+    if (k[r] != 0xFFFFFFFFu) pairs[s_bin[(k[r] - kmin) >> shift] + slot[r]] = ((unsigned long long)k[r] << 32) | (uint32_t)(r * NT + tid);
+  __syncthreads();
+  const uint32_t nv = s_bin[BINS];
+  if (tid == 0) n_vis[view] = nv;
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    if (k[r] != 0xFFFFFFFFu) {
+      const uint32_t i = (uint32_t)(r * NT + tid);
+      const unsigned long long mine = ((unsigned long long)k[r] << 32) | i;
+      const uint32_t bin = (k[r] - kmin) >> shift;
+      const uint32_t s0 = s_bin[bin], s1 = s_bin[bin + 1];
+      uint32_t rank = s0;
+      for (uint32_t j = s0; j < s1; ++j) rank += pairs[j] < mine ? 1u : 0u;
+      sorted_id[base + rank] = i;
+      sorted_rect[base + rank] = rect[base + i];
+    }
+  }
+  for (int i = (int)nv + tid; i < P; i += NT) { sorted_id[base + i] = 0u; sorted_rect[base + i] = make_uint2(0u, 0u); }
+  return true;
+}
+
+template <int NT, bool TRY_RANK>
+__global__ __launch_bounds__(NT) void depth_sort_block_radix_kernel(U3DSpan span, int N, const float* __restrict__ depth,
+                                                                    const int32_t* __restrict__ radii,
+                                                                    const uint2* __restrict__ rect,
+                                                                    uint32_t* __restrict__ sorted_id,
+                                                                    uint2* __restrict__ sorted_rect,
+                                                                    uint32_t* __restrict__ n_vis) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // keys[2][N], vals[2][N]  (or the rank path's pairs[N])
+  if constexpr (TRY_RANK) {
+    if (block_rank_sort<NT>(span, N, depth, radii, rect, sorted_id, sorted_rect, n_vis, lds)) return;
+  }
+  block_radix_sort<NT>(span, N, depth, radii, rect, sorted_id, sorted_rect, n_vis, lds);
 }
 
 // ---- large P: a coarse most-significant-digit partition, then every bucket sub-binned and ranked by its own workgroup --------
@@ -319,7 +419,7 @@ __global__ __launch_bounds__(NT) void bucket_sort_kernel(U3DSpan span, uint32_t*
   const int n = (int)(end - start);
   if (n == 0) return;
   if (n == 1) {
-    if (tid == 0) { const uint32_t v = vals0[base + start]; sorted_id[base + start] = v; sorted_rect[base + start] = rect[base + v]; }
+    if (tid == 0) sorted_id[base + start] = vals0[base + start];
     return;
   }
   bool fallback = n > CAP || bucket == MSD_BINS - 1;
@@ -375,9 +475,7 @@ __global__ __launch_bounds__(NT) void bucket_sort_kernel(U3DSpan span, uint32_t*
         const uint32_t s0 = s_sub[sub], s1 = s_sub[sub + 1];
         uint32_t rank = s0;
         for (uint32_t j = s0; j < s1; ++j) rank += s_pair[j] < mine ? 1u : 0u;
-        const uint32_t id = (uint32_t)mine;
-        sorted_id[base + start + rank] = id;
-        sorted_rect[base + start + rank] = rect[base + id];
+        sorted_id[base + start + rank] = (uint32_t)mine;   // (the tile kernels read the rectangle through the id: u3d_rect_indirect)
       }
       return;
     }
@@ -411,11 +509,7 @@ __global__ __launch_bounds__(NT) void bucket_sort_kernel(U3DSpan span, uint32_t*
         wg_radix_pass<NT, BITS>(ki, vi, ko, vo, n, BITS * (p - idx_passes), digit_base, wave_cnt);
     }
     const uint32_t* vf = (passes & 1) ? v1 : v0;
-    for (int i = tid; i < n; i += NT) {
-      const uint32_t id = vf[i];
-      sorted_id[base + start + i] = id;
-      sorted_rect[base + start + i] = rect[base + id];
-    }
+    for (int i = tid; i < n; i += NT) sorted_id[base + start + i] = vf[i];
   }
 }
 
@@ -426,19 +520,19 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
   if (d.P <= U3D_LDS_SORT_MAX) {
     {
       // 1024 threads once there is more than one round of them (16 waves hide the LDS / barrier latency of a lone workgroup)
-      const int NT = d.P > 1024 ? 1024 : 256;
+      const int NT = 1024;   // (one thread per linear depth bin of the rank path; the radix fallback wants 16 waves anyway)
       const int N = (d.P + NT - 1) / NT * NT;
       static bool attr_set = false;
       if (!attr_set) {   // up to 64 KiB of dynamic LDS (N = 4096) on top of the static arrays
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(depth_sort_block_radix_kernel<1024>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(depth_sort_block_radix_kernel<1024, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * U3D_LDS_SORT_MAX * (int)sizeof(uint32_t));
         attr_set = true;
       }
       if (NT == 1024)
-        hipLaunchKernelGGL(depth_sort_block_radix_kernel<1024>, dim3(NV), dim3(1024), (size_t)4 * N * sizeof(uint32_t), s, u3d_span(d), N, b.depth,
+        hipLaunchKernelGGL((depth_sort_block_radix_kernel<1024, true>), dim3(NV), dim3(1024), (size_t)4 * N * sizeof(uint32_t), s, u3d_span(d), N, b.depth,
                            radii, b.rect, b.sorted_id, b.sorted_rect, b.n_vis);
       else
-        hipLaunchKernelGGL(depth_sort_block_radix_kernel<256>, dim3(NV), dim3(256), (size_t)4 * N * sizeof(uint32_t), s, u3d_span(d), N, b.depth,
+        hipLaunchKernelGGL((depth_sort_block_radix_kernel<256, false>), dim3(NV), dim3(256), (size_t)4 * N * sizeof(uint32_t), s, u3d_span(d), N, b.depth,
                            radii, b.rect, b.sorted_id, b.sorted_rect, b.n_vis);
     }
     return;
