@@ -69,6 +69,8 @@ def _lib(dtype):
         getattr(lib, pre + "mark_visible").argtypes = [ctypes.c_int, vp, vp, vp, vp]
         getattr(lib, pre + "mark_visible").restype = None
         getattr(lib, pre + "num_threads").restype = ctypes.c_int
+        getattr(lib, pre + "set_num_threads").argtypes = [ctypes.c_int]
+        getattr(lib, pre + "set_num_threads").restype = None
         _libs[dtype] = (lib, pre, real)
     return _libs[dtype]
 
@@ -76,6 +78,13 @@ def _lib(dtype):
 def num_threads() -> int:
     lib, pre, _ = _lib(np.float32)
     return int(getattr(lib, pre + "num_threads")())
+
+
+def set_num_threads(n: int) -> None:
+    """OpenMP threads of the CALLING thread's next oracle calls (both precisions)."""
+    for dt in (np.float32, np.float64):
+        lib, pre, _ = _lib(dt)
+        getattr(lib, pre + "set_num_threads")(int(n))
 
 
 def _arr(x, dtype, shape=None):

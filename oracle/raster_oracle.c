@@ -779,6 +779,16 @@ void FN(mark_visible)(int P, const REAL *means3D, const REAL *viewmatrix, const 
   }
 }
 
+/* OpenMP threads of the CALLING thread's next parallel regions (per-thread ICV): bench.py's cpu_baseline leg renders one view per
+ * host thread with the inner regions serial, which is how a CPU renders 128 small views -- not 128 threads forking inside each. */
+void FN(set_num_threads)(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+#else
+  (void)n;
+#endif
+}
+
 int FN(num_threads)(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -288,6 +288,36 @@ def _tile_flags(sc):
     return (tl & 0x7fffffff, (tl >> 31).astype(bool)), radii[0].cpu().numpy()
 
 
+@pytest.mark.parametrize("P,H,W,level", [(128, 256, 256, "object"), (2048, 256, 256, "object"), (6000, 120, 160, "scene"), (300, 50, 70, "scene")])
+def test_num_rendered_equals_oracle(oracle_mod, P, H, W, level):
+    """`num_rendered` = sum over Gaussians of tiles touched (what the original operator copies back to the host on every forward;
+    here a statistics counter under U3D_FLAG_STATS) is an INTEGER output: it follows from the radii and tile rectangles, which the
+    forward projection reproduces bit for bit, so it equals the fp32 oracle's exactly -- at C2's and C3's per-view shapes too."""
+    import ctypes
+    from unipre3d_amd import _lib
+    from unipre3d_amd.rasterizer import _Plan
+    dev = torch.device("cuda:0")
+    sc = scene(P, H, W, seed=77, level=level, compact=False, deg=1)
+    t = {k: (v.to(dev).contiguous() if torch.is_tensor(v) else v) for k, v in sc.items()}
+    M = t["shs"].shape[1]
+    plan = _Plan(1, 1, P, H, W, sc["tanfovx"], sc["tanfovy"], 1.0, sc["sh_degree"], M, _lib.FLAG_ANTIALIASING | _lib.FLAG_DEBUG | _lib.FLAG_STATS)
+    u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+    geom, binning, image = u8(plan.sizes.geom_bytes), u8(plan.sizes.binning_bytes), u8(plan.sizes.image_bytes)
+    color, radii = torch.empty(1, 3, H, W, device=dev), torch.zeros(1, P, dtype=torch.int32, device=dev)
+    p = _lib.ptr
+    rc = _lib.load().u3d_rasterize_forward(ctypes.byref(plan.desc), p(t["bg"]), p(t["means3D"]), p(t["shs"]), p(None), p(t["opacities"]),
+                                           p(t["scales"]), p(t["rotations"]), p(None), p(t["viewmatrix"]), p(t["projmatrix"]), p(t["campos"]),
+                                           p(color), p(None), p(radii), p(geom), p(binning), p(image),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "u3d_rasterize_forward")
+    torch.cuda.synchronize()
+    off = plan.sizes.num_rendered_offset
+    nr = int(geom[off:off + 4].view(torch.int32).item())
+    r = oracle_mod.forward(dtype=np.float32, **to_numpy(sc))
+    assert np.array_equal(radii[0].cpu().numpy(), r.radii)
+    assert nr == int(r.num_rendered), (nr, int(r.num_rendered))
+
+
 @pytest.mark.parametrize("P,fade,every", [(200, 1.0, 7), (700, 0.05, 50), (700, 0.05, 333)])
 def test_loop_variants_high_opacity(oracle_mod, P, fade, every):
     """The tile kernels run a loop variant without the 0.99 clamp / pw test while every staged Gaussian has opacity <= 0.98
