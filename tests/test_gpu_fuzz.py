@@ -11,6 +11,9 @@ from arbiter import assert_parity, head_grad_arbiter_all
 from test_gpu_parity import TOL, _run_gpu, near
 
 pytestmark = pytest.mark.gpu
+# the same allowance over the fp32 restatement's own distance as every other test (arbiter.GAP_K = 2; rounds 1-2 needed 4 here because
+# the restatement's multi-threaded gradient sum changed from run to run -- its tile schedule is deterministic since round 3)
+FUZZ_K = 2.0
 
 
 def _cases(n=24, seed=20260928):
@@ -38,9 +41,8 @@ def test_fuzz_forward_backward_vs_oracle(oracle_mod, P, H, W, level, compact, de
     for k in DIFF_KEYS + ("means2D",):
         a = g[k].reshape(g32[k].shape)
         # bar: 1e-4 of the fp64 arbiter, or -- ill-conditioned draws (a handful of huge splats), where fp32 arithmetic itself sits
-        # ~1e-4 from fp64 whatever its summation order (the restatement's gradient sum is multi-threaded: 4-8e-5 run to run on the
-        # P = 7 draw, the kernels 1.2-1.35e-4) -- 4 x the fp32 restatement's own measured distance from it
-        assert_parity(a, g32[k], g64[k], f"{k} P={P} {H}x{W} {level}", k=4.0)
+        # ~1e-4 from fp64 whatever its summation order -- 2 x the fp32 restatement's own measured distance from it
+        assert_parity(a, g32[k], g64[k], f"{k} P={P} {H}x{W} {level}", k=FUZZ_K)
 
 
 def test_fuzz_fused_paths_agree_on_random_shapes(oracle_mod):
@@ -80,5 +82,5 @@ def test_fuzz_fused_paths_agree_on_random_shapes(oracle_mod):
             # both HIP routes against the fp64 arbiter of the whole chain (reference activations -> oracle -> reference loss)
             a32, _ = head_grad_arbiter_all(oracle_mod, bh, H, W, kind, np.float32)
             a64, _ = head_grad_arbiter_all(oracle_mod, bh, H, W, kind, np.float64)
-            assert_parity(res[0][2].permute(0, 2, 1).cpu().numpy(), a32, a64, f"fused {tag}", k=4.0)
-            assert_parity(gu.permute(0, 2, 1).cpu().numpy(), a32, a64, f"operator chain {tag}", k=4.0)
+            assert_parity(res[0][2].permute(0, 2, 1).cpu().numpy(), a32, a64, f"fused {tag}", k=FUZZ_K)
+            assert_parity(gu.permute(0, 2, 1).cpu().numpy(), a32, a64, f"operator chain {tag}", k=FUZZ_K)

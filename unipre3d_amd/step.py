@@ -52,8 +52,13 @@ def train_step(model: torch.nn.Module, feats: torch.Tensor, batch: SyntheticBatc
         loss, _ = render_loss_forward(raw, batch, H, W, input_images, loss_kind, render_fn)
     loss.backward()
     if clip_grad is not None:
-        from .gradcheck import check_and_clip_gradients
-        if not check_and_clip_gradients(model.parameters(), clip_grad):   # NaN/Inf: skip the step (train_network.py:336-340)
+        from .gradcheck import check_and_clip_deferred, check_and_clip_gradients
+        params = [p for p in model.parameters() if p.grad is not None]
+        if params and params[0].grad.is_cuda and optimizer.defaults.get("fused"):
+            # fused optimizer on a HIP device: the NaN / Inf decision stays on the device (`found_inf` makes the optimizer skip the
+            # step exactly when the reference's `if not valid: skip` would, train_network.py:336-340) -- no host read in the step
+            check_and_clip_deferred(params, optimizer, clip_grad)
+        elif not check_and_clip_gradients(params, clip_grad):   # NaN/Inf: skip the step
             optimizer.zero_grad(set_to_none=True)
             return loss.detach()
     optimizer.step()
