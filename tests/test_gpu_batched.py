@@ -629,3 +629,44 @@ def test_gradclip_deferred_drives_fused_adamw_without_a_host_read():
             assert all(rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 1e-6 for x, y in zip(pa, pb)), (poison, it)
         if poison:      # iteration 1 was skipped: parameters equal those after iteration 0
             assert all(torch.equal(x, y) for x, y in zip(b[0], b[1]))
+
+
+def test_fused_step_is_capturable_in_a_hip_graph():
+    """The fused step (render_loss_fused + loss.backward()) holds no host synchronisation and sizes everything from shapes, so it
+    can be captured in a HIP graph (torch.cuda.CUDAGraph) and replayed on new head outputs copied into the static input: loss and
+    gradient of the replay are bit-identical to the eager step (object level: fixed-order reductions).  tools/graph_probe.py
+    times it: the host-bound C1 step goes from 0.143 to 0.058 ms."""
+    from unipre3d_amd import fused
+    _, b = _batch(2, 128, 2, 64, 64, level="object", seed=41)
+    _, b2 = _batch(2, 128, 2, 64, 64, level="object", seed=42)
+    static_h = b.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+
+    def run(h):
+        loss, _, _ = fused.render_loss_fused(h, b.center, b.world_view, b.full_proj, b.camera_center, b.gt, b.bg, b.fov_deg, 64, 64,
+                                             level="object", offset_scale=b.offset_scale, loss_kind="focal_l2", return_images=False)
+        loss.backward()
+        return loss
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                      # warm-up on a side stream, as torch's capture recipe asks
+        for _ in range(3):
+            static_h.grad = None
+            run(static_h)
+    torch.cuda.current_stream().wait_stream(s)
+    static_h.grad = None
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_loss = run(static_h)
+    for src in (b2, b):
+        with torch.no_grad():
+            static_h.copy_(src.raw.permute(0, 2, 1))
+        g.replay()
+        torch.cuda.synchronize()
+        h = src.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+        l = run(h)
+        torch.cuda.synchronize()
+        assert torch.equal(static_loss.detach(), l.detach()) and torch.equal(static_h.grad, h.grad)
+    del g
+    from unipre3d_amd import rasterizer
+    rasterizer._C().clear_workspaces()              # (the cached scratch may live in the destroyed graph's private pool)
