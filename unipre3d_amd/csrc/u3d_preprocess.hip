@@ -775,8 +775,11 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
                                const float* projmatrix, const float* campos, int32_t* radii, double* acc_zero, hipStream_t s) {
   const bool fuse_sort = u3d_preprocess_sorts(d);
   const size_t NG = (size_t)d.views_per_item * u3d_total_P(d);
-  // enough Gaussians to fill the chip by themselves -> one thread walks all views of its set; otherwise split the views
-  const int vpt = (u3d_total_P(d) >= 65536) ? d.views_per_item : 1;
+  // enough Gaussians to fill the chip by themselves -> one thread walks several views of its set (the view-independent work --
+  // head activations, Sigma, SH fetch -- is done once per thread); otherwise one view per thread.  Four views per thread measured
+  // best at scene level (C4: 25.4 us with 1 or 8, 21.2 with 2 or 4; C5: 49.9 / 39.0 / 35.7 / 37.0 us with 1 / 2 / 4 / 8): the thread's
+  // view loop is a chain of dependent stores, and 314 workgroups (C4 with all 8 views per thread) leave most of the chip idle
+  const int vpt = (u3d_total_P(d) >= 65536) ? (d.views_per_item < 4 ? d.views_per_item : 4) : 1;
   const int chunks = (d.views_per_item + vpt - 1) / vpt;
   dim3 grid((d.P + U3D_BLOCK - 1) / U3D_BLOCK, d.n_items, chunks), block(U3D_BLOCK);
   const size_t lds = src.act != 0 ? (size_t)U3D_BLOCK * src.s_means * sizeof(float) : 0;
