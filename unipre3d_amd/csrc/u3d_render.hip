@@ -713,7 +713,10 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
 // One thread per (position, component) element of a tile's [64][10] block, so a tile is one contiguous read; only the
 // positions some tile of the slice touched (cmax, usually ~20 of 64) are read at all.
 constexpr int REDUCE_THREADS = U3D_WAVE * 10;
-#define RU 32   // tiles in flight per thread
+// tiles in flight per thread: 32 in the single-block kernel (object level), 16 in the generic one (measured, tools/sweep_ru.sh:
+// C3 10.1 -> 9.3 us, C4 17.0 -> 15.5, C5 13.0 -> 11.8 with 16; C2 11.3 -> 11.6; 64 is slower everywhere)
+#define RU 16
+#define RU1 32
 template <int PB>
 __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(U3DSpan span, int T, int NK, int nsplit, size_t NG, float half_w, float half_h,
                                                                    const uint32_t* __restrict__ sorted_id,
@@ -880,16 +883,16 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce1_kernel(U3DSpan spa
     // whole group of tiles is in flight at once; accumulation order stays ascending in t within each of the two chains
     double a0 = 0.0, a1 = 0.0;
     int t = t0;
-    for (; t + RU - 1 < t1; t += RU) {
-      float v[RU];
-      uint32_t c[RU];
+    for (; t + RU1 - 1 < t1; t += RU1) {
+      float v[RU1];
+      uint32_t c[RU1];
 #pragma unroll
-      for (int u = 0; u < RU; ++u) {
+      for (int u = 0; u < RU1; ++u) {
         c[u] = cnt[t + u];
         v[u] = base[(size_t)(t + u) * (U3D_WAVE * 10)];
       }
 #pragma unroll
-      for (int u = 0; u < RU; u += 2) {
+      for (int u = 0; u < RU1; u += 2) {
         a0 += (uint32_t)sp < c[u] ? (double)v[u] : 0.0;
         a1 += (uint32_t)sp < c[u + 1] ? (double)v[u + 1] : 0.0;
       }
