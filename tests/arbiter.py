@@ -71,12 +71,12 @@ class _OracleRender(torch.autograd.Function):
     """The CPU oracle as a differentiable renderer (one view) for torch autograd on CPU tensors of either dtype."""
 
     @staticmethod
-    def forward(ctx, oracle_mod, means3D, opacities, scales, rotations, shs, view, proj, campos, bg, H, W, t, sh_degree, exact_aa):
+    def forward(ctx, oracle_mod, means3D, opacities, scales, rotations, shs, view, proj, campos, bg, H, W, t, sh_degree, exact_aa, antialiasing=True):
         dt = np.float32 if means3D.dtype == torch.float32 else np.float64
         n = lambda x: np.ascontiguousarray(x.detach().numpy())
         r = oracle_mod.forward(n(means3D), n(opacities), n(view).astype(dt), n(proj).astype(dt), n(campos).astype(dt), n(bg).astype(dt),
                                H, W, t, t, shs=n(shs), scales=n(scales), rotations=n(rotations), sh_degree=sh_degree, dtype=dt,
-                               exact_aa_grad=exact_aa)
+                               exact_aa_grad=exact_aa, antialiasing=antialiasing)
         ctx.r, ctx.oracle_mod, ctx.tdt = r, oracle_mod, means3D.dtype
         return torch.from_numpy(r.color.copy())
 
@@ -85,11 +85,11 @@ class _OracleRender(torch.autograd.Function):
         go = ctx.oracle_mod.backward(ctx.r, np.ascontiguousarray(gcol.numpy()))
         ctx.r.close()
         f = lambda k: torch.from_numpy(np.ascontiguousarray(go[k])).to(ctx.tdt)
-        return (None, f("means3D"), f("opacities"), f("scales"), f("rotations"), f("shs")) + (None,) * 9
+        return (None, f("means3D"), f("opacities"), f("scales"), f("rotations"), f("shs")) + (None,) * 10
 
 
 def head_grad_arbiter(oracle_mod, b, bi, v, H, W, n_views_total, loss_kind, dtype=np.float64, sh_degree=1,
-                      non_bg_rate=4.0, bg_rate=1.0, exact_aa_grad=False, loss_scale=1.0):
+                      non_bg_rate=4.0, bg_rate=1.0, exact_aa_grad=False, loss_scale=1.0, antialiasing=True):
     """d loss / d raw[bi] ((C, P), the reference's (B, 23, N) layout) where loss = render loss over ALL n_views_total views'
     pixels but only view (bi, v) differs from its target -- i.e. the per-view contribution the fused kernels can be made to
     isolate by setting gt = rendered for every other view.  Returns (gradient (C,P) ndarray, loss value, image (3,H,W))."""
@@ -109,7 +109,7 @@ def head_grad_arbiter(oracle_mod, b, bi, v, H, W, n_views_total, loss_kind, dtyp
     shs = head.concat_sh(g["features_dc"], g["features_rest"])
     c = lambda x: x.detach().cpu()
     img = _OracleRender.apply(oracle_mod, g["xyz"], g["opacity"], g["scaling"], g["rotation"], shs, c(b.world_view[bi, v]),
-                              c(b.full_proj[bi, v]), c(b.camera_center[bi, v]), c(b.bg), H, W, t, sh_degree, exact_aa_grad)
+                              c(b.full_proj[bi, v]), c(b.camera_center[bi, v]), c(b.bg), H, W, t, sh_degree, exact_aa_grad, antialiasing)
     gt = c(b.gt[bi, v]).to(tdt)
     white = bool(b.bg[0].item() > 0.5) if loss_kind == "focal_l2" else False
     # the loss of this one view, re-normalised to the whole batch's pixel count (the other views contribute exact zeros)
@@ -121,7 +121,7 @@ def head_grad_arbiter(oracle_mod, b, bi, v, H, W, n_views_total, loss_kind, dtyp
     return raw.grad[0].numpy().copy() / loss_scale, float(loss.item()), img.detach().numpy().copy()
 
 
-def head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, dtype=np.float64, sh_degree=1, input_images=0, loss_scale=1.0):
+def head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, dtype=np.float64, sh_degree=1, input_images=0, loss_scale=1.0, antialiasing=True):
     """d loss / d raw for the WHOLE batch ((B, C, P)): the per-view arbiters summed over every item's views (small shapes only:
     one oracle render per view).  Also returns the loss value."""
     B, V = b.raw.shape[0], b.world_view.shape[1] - input_images
@@ -129,7 +129,7 @@ def head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, dtype=np.float64, sh_d
     for bi in range(B):
         acc = None
         for v in range(input_images, input_images + V):
-            g, l, _ = head_grad_arbiter(oracle_mod, b, bi, v, H, W, B * V, loss_kind, dtype, sh_degree, loss_scale=loss_scale)
+            g, l, _ = head_grad_arbiter(oracle_mod, b, bi, v, H, W, B * V, loss_kind, dtype, sh_degree, loss_scale=loss_scale, antialiasing=antialiasing)
             acc = g if acc is None else acc + g
             loss += l
         out.append(acc)
