@@ -38,7 +38,8 @@ def test_head_grad_arbiter_matches_autograd_of_the_whole_chain(oracle_mod, level
     assert rel_l2(g32, ga) < 1e-3
 
 
-def test_g10_chain_known_answers_pin_the_arbiter(golden, oracle_mod):
+@pytest.mark.parametrize("level,kind,fname", [("object", "focal_l2", "g10_chain.npz"), ("scene", "l2", "g10_chain_scene.npz")])
+def test_g10_chain_known_answers_pin_the_arbiter(golden, oracle_mod, level, kind, fname):
     """tests/golden/make_g10_chain.py: loss and d loss / d head_out of the WHOLE chain (reference activations incl. the across-point
     quaternion quirk -> render -> focal-L2), evaluated by an independent float64 numpy transcription and central differences over all
     P x 23 head entries, without oracle/ or the product.  The fp64 arbiter chain (head.py -> oracle -> losses.py) must hit it --
@@ -46,15 +47,15 @@ def test_g10_chain_known_answers_pin_the_arbiter(golden, oracle_mod):
     import torch
     from arbiter import head_grad_arbiter_all
     from unipre3d_amd import synthetic
-    g = golden("g10_chain.npz")
+    g = golden(fname)
     H, W = int(g["H"]), int(g["W"])
     T = lambda k: torch.from_numpy(np.asarray(g[k]))
     b = synthetic.SyntheticBatch(raw=T("head_out").permute(0, 2, 1).contiguous(), center=T("center"), world_view=T("world_view"),
                                  full_proj=T("full_proj"), camera_center=T("camera_center"), gt=T("gt"), bg=T("bg"), fov_deg=float(g["fov_deg"]),
-                                 level="object", offset_scale=float(g["offset_scale"]))
+                                 level=level, offset_scale=float(g["offset_scale"]))
     for dt, tol in ((np.float64, 1e-7), (np.float32, 2e-5)):
-        a, l = head_grad_arbiter_all(oracle_mod, b, H, W, "focal_l2", dt, antialiasing=False)
+        a, l = head_grad_arbiter_all(oracle_mod, b, H, W, kind, dt, antialiasing=False)
         e = rel_l2(a[0].T, g["d_head"][0])
         assert abs(l - float(g["loss"])) <= (1e-12 if dt == np.float64 else 1e-6) * max(1.0, abs(float(g["loss"]))) or abs(l - float(g["loss"])) < 1e-7, (l, float(g["loss"]))
         assert e < tol, (dt, e)
-        print("g10 chain", dt.__name__, f"{e:.1e}")
+        print("g10 chain", level, dt.__name__, f"{e:.1e}")

@@ -672,27 +672,28 @@ def test_fused_step_is_capturable_in_a_hip_graph():
     rasterizer._C().clear_workspaces()              # (the cached scratch may live in the destroyed graph's private pool)
 
 
+@pytest.mark.parametrize("level,kind,fname", [("object", "focal_l2", "g10_chain.npz"), ("scene", "l2", "g10_chain_scene.npz")])
 @pytest.mark.parametrize("single_pass", [True, False])
-def test_g10_chain_known_answers(golden, single_pass):
+def test_g10_chain_known_answers(golden, single_pass, level, kind, fname):
     """The fused HIP step against tests/golden/g10_chain.npz: loss and d loss / d head_out of the whole chain (activations incl. the
     across-point quaternion quirk -> render -> focal-L2) from an independent float64 numpy transcription and central differences over
     all P x 23 head entries (tests/golden/make_g10_chain.py imports neither oracle/ nor the product).  Anti-aliasing off: the published
     backward differentiates the AA factor inexactly on purpose."""
     from unipre3d_amd import fused
-    g = golden("g10_chain.npz")
+    g = golden(fname)
     dev = torch.device("cuda:0")
     T = lambda k: torch.from_numpy(np.asarray(g[k])).to(dev)
     H, W = int(g["H"]), int(g["W"])
     h = T("head_out").contiguous().requires_grad_(True)
     loss, img, _ = fused.render_loss_fused(h, T("center"), T("world_view"), T("full_proj"), T("camera_center"), T("gt"), T("bg"), float(g["fov_deg"]), H, W,
-                                           level="object", offset_scale=float(g["offset_scale"]), loss_kind="focal_l2", antialiasing=False,
+                                           level=level, offset_scale=float(g["offset_scale"]), loss_kind=kind, antialiasing=False,
                                            single_pass=single_pass, debug=True)
     loss.backward()
     torch.cuda.synchronize()
     assert abs(loss.item() - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
     assert rel_l2(img.cpu().numpy(), g["images"]) < 2e-6
     e = rel_l2(h.grad.cpu().numpy(), g["d_head"])
-    print(f"g10 chain (single_pass={single_pass}): d head_out rel-L2 {e:.1e}")
+    print(f"g10 chain {level} (single_pass={single_pass}): d head_out rel-L2 {e:.1e}")
     assert e < 2e-5
     for lo, hi in ((0, 3), (3, 4), (4, 7), (7, 11), (11, 14), (14, 23)):     # every channel group on its own
         assert rel_l2(h.grad[..., lo:hi].cpu().numpy(), g["d_head"][..., lo:hi]) < 1e-4, (lo, hi)
