@@ -49,6 +49,7 @@ struct U3DBuffers {
   uint32_t* n_vis;       // [NV]   number of entries of the sorted list that are on screen
   uint32_t* sort_keys[2];  // [NV*P] x2  radix ping-pong (large P only)
   uint32_t* sort_vals[2];  // [NV*P] x2
+  uint2* sort_pairs;       // [NV*P] (key, index) pairs as the partition writes them: one 8-byte store per pair (large P only)
   uint32_t* sort_hist;     // bucket totals [NV][512] (zeroed by preprocess_fwd), then per-workgroup slice offsets [NV][blocks][512]
   uint32_t* sort_over;     // bucket start table [NV][513]
   // image
@@ -199,11 +200,13 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
     CARVE(bn, sort_keys[1], uint32_t, NG);
     CARVE(bn, sort_vals[0], uint32_t, NG);
     CARVE(bn, sort_vals[1], uint32_t, NG);
+    CARVE(bn, sort_pairs, uint2, NG);
     const size_t nblk = ((size_t)d.P + u3d_radix_tile(d.P) - 1) / u3d_radix_tile(d.P);
     CARVE(bn, sort_hist, uint32_t, NV * (size_t)u3d_msd_bins(d.P) * (nblk + 1));
     CARVE(bn, sort_over, uint32_t, NV * ((size_t)u3d_msd_bins(d.P) + 1));
   } else if (b) {
     b->sort_keys[0] = b->sort_keys[1] = b->sort_vals[0] = b->sort_vals[1] = b->sort_hist = b->sort_over = nullptr;
+    b->sort_pairs = nullptr;
   }
   L.binning_bytes = o > 0 ? o : 256;
   o = 0;

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NT) void msd_hist_kernel(U3DSpan span, int nblk, co
 
 template <int NT, int ITEMS, int SHIFT>
 __global__ __launch_bounds__(NT) void msd_scatter_kernel(U3DSpan span, int nblk, const float* __restrict__ depth,
-                                                         uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                         uint2* __restrict__ pairs_out,
                                                          const uint32_t* __restrict__ total, const uint32_t* __restrict__ slice_off,
                                                          uint32_t* __restrict__ n_vis, uint32_t* __restrict__ bucket_off) {
   constexpr int MSD_BINS = Msd<SHIFT>::BINS;
@@ -326,8 +326,7 @@ __global__ __launch_bounds__(NT) void msd_scatter_kernel(U3DSpan span, int nblk,
         const uint32_t k = __float_as_uint(z) - MSD_KEY_BASE;
         const uint32_t bkt = msd_bucket<SHIFT>(k);
         const uint32_t dst = s_base[bkt] + atomicAdd(&s_cnt[bkt], 1u);
-        keys_out[base + dst] = k;
-        vals_out[base + dst] = (uint32_t)idx;
+        pairs_out[base + dst] = make_uint2(k, (uint32_t)idx);   // one 8-byte store per pair
       }
     }
   }
@@ -398,8 +397,8 @@ __device__ __forceinline__ void wg_radix_pass(const uint32_t* kin, const uint32_
 __device__ __forceinline__ unsigned long long pair64(uint32_t k, uint32_t v) { return ((unsigned long long)k << 32) | v; }
 
 template <int NT, int ITEMS, int SHIFT>   // 256 x 8 = 2048 pairs in LDS
-__global__ __launch_bounds__(NT) void bucket_sort_kernel(U3DSpan span, uint32_t* __restrict__ keys0, uint32_t* __restrict__ vals0,
-                                                         uint32_t* __restrict__ keys1, uint32_t* __restrict__ vals1,
+__global__ __launch_bounds__(NT) void bucket_sort_kernel(U3DSpan span, const uint2* __restrict__ pairs, uint32_t* __restrict__ keys0,
+                                                         uint32_t* __restrict__ vals0, uint32_t* __restrict__ keys1, uint32_t* __restrict__ vals1,
                                                          const uint32_t* __restrict__ bucket_off, const uint2* __restrict__ rect,
                                                          uint32_t* __restrict__ sorted_id, uint2* __restrict__ sorted_rect) {
   constexpr int BITS = 6, CAP = NT * ITEMS, MSD_BINS = Msd<SHIFT>::BINS, MSD_SHIFT = SHIFT, SUB_SHIFT = SHIFT - SUB_BITS;
@@ -419,7 +418,7 @@ __global__ __launch_bounds__(NT) void bucket_sort_kernel(U3DSpan span, uint32_t*
   const int n = (int)(end - start);
   if (n == 0) return;
   if (n == 1) {
-    if (tid == 0) sorted_id[base + start] = vals0[base + start];
+    if (tid == 0) sorted_id[base + start] = pairs[base + start].y;
     return;
   }
   bool fallback = n > CAP || bucket == MSD_BINS - 1;
@@ -433,8 +432,9 @@ __global__ __launch_bounds__(NT) void bucket_sort_kernel(U3DSpan span, uint32_t*
     for (int r = 0; r < ITEMS; ++r) {
       const int i = r * NT + tid;
       if (i < n) {
-        k[r] = keys0[base + start + i];
-        v[r] = vals0[base + start + i];
+        const uint2 kv = pairs[base + start + i];
+        k[r] = kv.x;
+        v[r] = kv.y;
         slot[r] = atomicAdd(&s_sub[(k[r] >> SUB_SHIFT) & (SUB_BINS - 1)], 1u);
       }
     }
@@ -496,10 +496,9 @@ __global__ __launch_bounds__(NT) void bucket_sort_kernel(U3DSpan span, uint32_t*
     uint32_t* const k1 = in_lds ? s_data + BUCKET_LDS_CAP : keys1 + base + start;
     uint32_t* const v0 = in_lds ? s_data + 2 * BUCKET_LDS_CAP : vals0 + base + start;
     uint32_t* const v1 = in_lds ? s_data + 3 * BUCKET_LDS_CAP : vals1 + base + start;
-    if (in_lds) {
-      for (int i = tid; i < n; i += NT) { k0[i] = keys0[base + start + i]; v0[i] = vals0[base + start + i]; }
-      __syncthreads();
-    }
+    for (int i = tid; i < n; i += NT) { const uint2 kv = pairs[base + start + i]; k0[i] = kv.x; v0[i] = kv.y; }   // un-zip (LDS or global)
+    __threadfence_block();
+    __syncthreads();
     for (int p = 0; p < passes; ++p) {
       uint32_t* ki = (p & 1) ? k1 : k0; uint32_t* ko = (p & 1) ? k0 : k1;
       uint32_t* vi = (p & 1) ? v1 : v0; uint32_t* vo = (p & 1) ? v0 : v1;
@@ -546,9 +545,9 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
 #define LAUNCH(NT, IT, SH)                                                                                                                    \
   do {                                                                                                                                        \
     hipLaunchKernelGGL((msd_hist_kernel<NT, IT, SH>), dim3(nblk, NV), dim3(NT), 0, s, u3d_span(d), nblk, b.depth, total, slice_off);          \
-    hipLaunchKernelGGL((msd_scatter_kernel<NT, IT, SH>), dim3(nblk, NV), dim3(NT), 0, s, u3d_span(d), nblk, b.depth, b.sort_keys[0],          \
-                       b.sort_vals[0], total, slice_off, b.n_vis, b.sort_over);                                                               \
-    hipLaunchKernelGGL((bucket_sort_kernel<256, 8, SH>), dim3(bins, NV), dim3(256), 0, s, u3d_span(d), b.sort_keys[0], b.sort_vals[0],        \
+    hipLaunchKernelGGL((msd_scatter_kernel<NT, IT, SH>), dim3(nblk, NV), dim3(NT), 0, s, u3d_span(d), nblk, b.depth, b.sort_pairs,            \
+                       total, slice_off, b.n_vis, b.sort_over);                                                                               \
+    hipLaunchKernelGGL((bucket_sort_kernel<256, 8, SH>), dim3(bins, NV), dim3(256), 0, s, u3d_span(d), b.sort_pairs, b.sort_keys[0], b.sort_vals[0], \
                        b.sort_keys[1], b.sort_vals[1], b.sort_over, b.rect, b.sorted_id, b.sorted_rect);                                      \
   } while (0)
   if (d.P <= 65536) LAUNCH(U3D_RADIX_NT_SMALL, U3D_RADIX_IT_SMALL, 18); else LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE, 17);
