@@ -240,3 +240,33 @@ def test_fuzz_ragged_fused_step():
             else:
                 assert not a.any(), tag
             o += n
+
+
+def test_render_views_takes_the_scene_branch_lists():
+    """GaussianSplatPredictor's scene branch returns per-item LISTS of (M_i, .) tensors (model/gaussian_predictor.py:331-364); the
+    reference's training loop cannot render those (`v.shape` on a list, train_network.py:423), its eval loop indexes them item by item
+    (eval.py:97-99).  renderer.render_views packs them and renders every scene of the rank in one launch sequence: images equal the
+    item-by-item renders bit for bit, and the gradient reaches the raw head output of every scene."""
+    from unipre3d_amd import head, renderer, synthetic
+    dev = torch.device("cuda:0")
+    V, H, W = 3, 48, 80
+    sizes = [700, 5000, 129]
+    bs = [synthetic.make_batch(1, n, V, H, W, level="scene", seed=90 + i).to(dev) for i, n in enumerate(sizes)]
+    raw = torch.cat([b.raw[0].t() for b in bs]).contiguous().requires_grad_(True)              # (sum M_i, 23) per-voxel head output
+    center = torch.cat([b.center[0] for b in bs])
+    idx = torch.cat([torch.full((n, 1), i, dtype=torch.long, device=dev) for i, n in enumerate(sizes)])
+    lists = head.process_scene_output(raw, center, idx, bs[0].offset_scale, 1)
+    assert isinstance(lists["xyz"], list) and [x.shape[0] for x in lists["xyz"]] == sizes
+    cat = lambda k: torch.cat([getattr(b, k) for b in bs])
+    out = renderer.render_views(lists, cat("world_view"), cat("full_proj"), cat("camera_center"), bs[0].bg, bs[0].fov_deg, H, W)
+    assert out.shape == (len(sizes) * V, 3, H, W)
+    for i, b in enumerate(bs):
+        one = {k: v[i][None] for k, v in lists.items()}
+        ref = renderer.render_views(one, b.world_view, b.full_proj, b.camera_center, b.bg, b.fov_deg, H, W)
+        assert torch.equal(out[i * V:(i + 1) * V], ref), i
+    gt = cat("gt").reshape(-1, 3, H, W)
+    ((out - gt) ** 2).mean().backward()
+    o = 0
+    for n in sizes:
+        assert torch.isfinite(raw.grad[o:o + n]).all() and raw.grad[o:o + n].abs().sum() > 0
+        o += n

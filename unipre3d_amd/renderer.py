@@ -62,11 +62,24 @@ def render_predicted(pc: Dict[str, torch.Tensor], world_view_transform, full_pro
 def render_views(gaussians: Dict[str, torch.Tensor], world_view: torch.Tensor, full_proj: torch.Tensor,
                  camera_center: torch.Tensor, bg: torch.Tensor, fov_deg: float, H: int, W: int, input_images: int = 0,
                  max_sh_degree: int = 1, scaling_modifier: float = 1.0) -> torch.Tensor:
-    """gaussians: dict of (B,P,...) tensors (head.process_object_output); cameras (B,Vtot,...).
+    """gaussians: dict of (B,P,...) tensors (head.process_object_output) -- or, scene level, of per-item LISTS of (M_i,...)
+    tensors as GaussianSplatPredictor returns them there (model/gaussian_predictor.py:331-364; head.process_scene_output): the
+    reference's own loop cannot take those (`v.shape` on a list, train_network.py:423), eval.py:97-99 indexes them per item;
+    here the sets of different sizes are packed and rendered in ONE launch sequence.  Cameras (B,Vtot,...).
     Returns (B*(Vtot-input_images), 3, H, W), ordered like train_network.py:418-446."""
-    B = gaussians["xyz"].shape[0]
     wv, fp, cc = world_view[:, input_images:], full_proj[:, input_images:], camera_center[:, input_images:]
     t = math.tan(fov_deg * math.pi / 360)  # same tan for x and y (gaussian_renderer/__init__.py:35-37)
+    if isinstance(gaussians["xyz"], (list, tuple)):
+        sizes = [int(x.shape[0]) for x in gaussians["xyz"]]
+        B = len(sizes)
+        cat = lambda k: torch.cat(list(gaussians[k]), dim=0)
+        rest = gaussians.get("features_rest")
+        shs = torch.cat([head.concat_sh(dc, rest[i] if rest is not None else None) for i, dc in enumerate(gaussians["features_dc"])], dim=0)
+        color, _, _ = rasterize_gaussians_batched(
+            cat("xyz"), cat("opacity"), wv, fp, cc, bg, H, W, t, t, shs=shs, scales=cat("scaling"), rotations=cat("rotation"),
+            sh_degree=max_sh_degree, scale_modifier=scaling_modifier, antialiasing=True, sizes=sizes)
+        return color.reshape(B * wv.shape[1], 3, H, W)
+    B = gaussians["xyz"].shape[0]
     shs = head.concat_sh(gaussians["features_dc"], gaussians.get("features_rest"))
     color, _, _ = rasterize_gaussians_batched(
         gaussians["xyz"], gaussians["opacity"], wv, fp, cc, bg, H, W, t, t, shs=shs, scales=gaussians["scaling"],
