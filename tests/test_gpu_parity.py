@@ -1,5 +1,7 @@
 """Parity proper: the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs.
 Tolerance (BASELINE.json north_star): 1e-4 relative L2 on images and gradients; radii are integers -> exact."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -430,3 +432,58 @@ def test_operator_refuses_inconsistent_shapes():
         rasterize_gaussians_batched(t["means3D"][None], t["opacities"][None], t["viewmatrix"][None, None].expand(1, 2, 4, 4)[:, :1], t["projmatrix"][None, None],
                                     t["campos"][None, None, :2], t["bg"], 20, 36, 0.5, 0.5, shs=t["shs"][None], scales=t["scales"][None],
                                     rotations=t["rotations"][None], sh_degree=1)
+
+
+@pytest.mark.parametrize("P,V", [(300, 2), (3000, 2), (70_000, 2), (1_000_000, 1)])
+def test_depth_sort_properties_at_scale(P, V):
+    """Size-independent properties of the per-view depth order, read straight from the scratch buffers of a forward over the C-ABI,
+    at sizes no oracle run reaches (every sort route: fused bitonic, linear-bin rank, bucketed rank with 512 and with 1024 buckets):
+    the first n_vis sorted ids are a PERMUTATION of the visible Gaussians, their depth bits are non-decreasing, ties come in
+    ascending index order (a tenth of the depths are made exactly equal), and n_vis equals the number of non-zero radii."""
+    import ctypes
+    from unipre3d_amd import _lib, synthetic
+    from unipre3d_amd.rasterizer import _Plan
+    dev = torch.device("cuda:0")
+    H, W = 64, 96
+    b = synthetic.make_batch(1, P, V, H, W, level="scene", seed=P % 97).to(dev)
+    g = synthetic.gaussians_from_batch(b)
+    xyz = g["xyz"][0].clone()
+    # exact depth ties: snap a tenth of the points onto a few planes of constant view-space depth of view 0
+    Vm = b.world_view[0, 0].double()
+    z = torch.cat([xyz.double(), torch.ones(P, 1, dtype=torch.float64, device=dev)], 1) @ Vm[:, 2]
+    sel = torch.arange(0, P, 10, device=dev)
+    target = torch.tensor([1.5, 2.25, 3.0], dtype=torch.float64, device=dev)[sel % 3]
+    xyz[sel] += ((target - z[sel])[:, None] * Vm[:3, 2][None, :]).float()
+    from unipre3d_amd import head
+    shs = head.concat_sh(g["features_dc"][0], g["features_rest"][0]).contiguous()
+    t = math.tan(b.fov_deg * math.pi / 360)
+    plan = _Plan(1, V, P, H, W, t, t, 1.0, 1, 4, _lib.FLAG_ANTIALIASING | _lib.FLAG_DEBUG)
+    u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+    geom, binning, image = u8(plan.sizes.geom_bytes), u8(plan.sizes.binning_bytes), u8(plan.sizes.image_bytes)
+    color, radii = torch.empty(V, 3, H, W, device=dev), torch.zeros(V, P, dtype=torch.int32, device=dev)
+    p = _lib.ptr
+    c = lambda x: x.contiguous()
+    rc = _lib.load().u3d_rasterize_forward(ctypes.byref(plan.desc), p(b.bg), p(c(xyz)), p(shs), p(None), p(c(g["opacity"][0])), p(c(g["scaling"][0])),
+                                           p(c(g["rotation"][0])), p(None), p(c(b.world_view[0]).reshape(V, 16)), p(c(b.full_proj[0]).reshape(V, 16)),
+                                           p(c(b.camera_center[0]).reshape(V, 3)), p(color), p(None), p(radii), p(geom), p(binning), p(image),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "u3d_rasterize_forward")
+    torch.cuda.synchronize()
+    al = lambda n: ((n + 255) // 256) * 256
+    NG = V * P
+    depth = geom[: 4 * NG].view(torch.float32).reshape(V, P)
+    sorted_id = binning[: 4 * NG].view(torch.int32).reshape(V, P).long()
+    o_nvis = al(4 * NG) + al(8 * NG)
+    n_vis = binning[o_nvis: o_nvis + 4 * V].view(torch.int32)
+    for v in range(V):
+        vis = radii[v] > 0
+        nv = int(n_vis[v].item())
+        assert nv == int(vis.sum().item()), (v, nv, int(vis.sum().item()))
+        ids = sorted_id[v, :nv]
+        assert torch.equal(torch.sort(ids).values, torch.nonzero(vis).flatten()), "sorted ids are not a permutation of the visible set"
+        keys = depth[v][ids].view(torch.int32).long()          # positive floats: bit order == value order
+        assert bool((keys[1:] >= keys[:-1]).all()), "depth bits decrease somewhere"
+        tie = keys[1:] == keys[:-1]
+        assert bool((ids[1:][tie] > ids[:-1][tie]).all()), "a depth tie is not in ascending index order"
+        if v == 0:
+            assert int(tie.sum().item()) > P // 200            # the planted ties are there (those in front of the near cull / on screen)
