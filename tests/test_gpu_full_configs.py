@@ -179,3 +179,35 @@ def test_one_million_gaussians_per_view_properties():
     assert (res[0][2] - res[2][2]).abs().max().item() <= 1e-6 * scale                      # (f64 atomics beyond the partial rows: order-insensitive)
     touched = int((res[0][2].abs().sum(dim=-1) > 0).sum().item())
     assert 0 < touched < 5000 and 0.3 * P < int((res[0][3] > 0).sum().item()) / V < P
+
+
+def test_backward_is_linear_in_the_cotangent_at_C4_shape():
+    """Size-independent property at a full BASELINE shape (C4: 2 sets x 40 000 Gaussians x 8 views, 480 x 640), no oracle needed:
+    the operator's backward is LINEAR in dL/dcolor -- grad(G1 + 2 G2) = grad(G1) + 2 grad(G2) for all six differentiable inputs (to
+    fp32 rounding of the sums), and a zero cotangent gives exactly zero gradients."""
+    from unipre3d_amd import head, synthetic
+    from unipre3d_amd.rasterizer import rasterize_gaussians_batched
+    dev = torch.device("cuda:0")
+    cfg = synthetic.CONFIGS["C4"]
+    B, P, V, H, W = cfg["B"], cfg["P"], cfg["V"], cfg["H"], cfg["W"]
+    bd = synthetic.make_batch(B, P, V, H, W, level="scene", seed=5).to(dev)
+    g0 = synthetic.gaussians_from_batch(bd)
+    t = math.tan(bd.fov_deg * math.pi / 360)
+    gen = torch.Generator().manual_seed(3)
+    G1 = torch.randn(B, V, 3, H, W, generator=gen).to(dev)
+    G2 = torch.randn(B, V, 3, H, W, generator=gen).to(dev)
+    keys = ("xyz", "opacity", "scaling", "rotation")
+
+    def grads(cot):
+        g = {k: g0[k].detach().clone().requires_grad_(True) for k in keys}
+        shs = head.concat_sh(g0["features_dc"], g0["features_rest"]).detach().clone().requires_grad_(True)
+        color, _, _ = rasterize_gaussians_batched(g["xyz"], g["opacity"], bd.world_view, bd.full_proj, bd.camera_center, bd.bg, H, W, t, t, shs=shs,
+                                                  scales=g["scaling"], rotations=g["rotation"], sh_degree=1)
+        (color * cot).sum().backward()
+        return [g[k].grad for k in keys] + [shs.grad]
+
+    a, b, c, z = grads(G1), grads(G2), grads(G1 + 2.0 * G2), grads(torch.zeros_like(G1))
+    for x, y, w, zero in zip(a, b, c, z):
+        ref = x + 2.0 * y
+        assert rel_l2(w.cpu().numpy(), ref.cpu().numpy()) < 2e-5
+        assert not zero.any()
