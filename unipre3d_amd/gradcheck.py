@@ -148,7 +148,9 @@ def check_and_clip_deferred(parameters: Iterable[torch.nn.Parameter], optimizer:
     """The same decision WITHOUT a host read, for torch's fused optimizers (AdamW(fused=True)): the optimizer's device-side
     `found_inf` makes it skip the step exactly when the reference would (`if not valid: skip`, train_network.py:336-340), and the
     gradients are scaled by the multi-tensor pass (which leaves at once when nothing is to be clipped).  Call instead of
-    `if check_and_clip_gradients(...): optimizer.step()`, then `optimizer.step()` unconditionally."""
+    `if check_and_clip_gradients(...): optimizer.step()`, then `optimizer.step()` unconditionally.  `optimizer.found_inf` stays a view
+    of this gradient set's state block: call this before EVERY step of that optimizer (a step without it would reuse the previous
+    decision), or reset `optimizer.found_inf = None` when switching back to the host-read form."""
     grads = _device_grads(parameters)
     if not grads:
         return
