@@ -54,7 +54,8 @@ def algorithmic_bytes(kind: str, P: int, R: float, T: int, HW: int) -> float:
     }[kind]
 
 
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
+PROFILE_FALLBACK_ROUND = "r03"
 # measured instruction-class issue costs on gfx950, cycles per wave64 instruction per SIMD (profiles/r01/valu_instruction_classes.txt,
 # tools/ub/ops.hip under rocprofv3 --pmc): FMA / MUL / ADD / MOV 2.13, compare / min / select / DPP 4.08, exp / rcp 8.1; a scalar
 # instruction costs the SIMD's issue port about 1.7 (profiles/r01/ub_mixed_streams.txt: fma + s_and = 1.8 x an fma alone)
@@ -63,8 +64,15 @@ N_SIMD, SHADER_CLOCK_HZ = 1024, 2.4e9     # MI355X: 256 CUs x 4 SIMDs; MI355X_MI
 
 
 def _profile_json(name: str):
-    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, name)
-    return json.load(open(path)) if os.path.exists(path) else None
+    """Newest committed profile of that name (this round's, else the previous round's: a kernel the round did not touch keeps its
+    pass); the round it came from travels with it (`_round`) into every source label."""
+    for rnd in (PROFILE_ROUND, PROFILE_FALLBACK_ROUND):
+        path = os.path.join(ROOT, "profiles", rnd, name)
+        if os.path.exists(path):
+            d = json.load(open(path))
+            d["_round"] = rnd
+            return d
+    return None
 
 
 def pmc_traffic(kernel: str, config: str, default_path: bool):
@@ -107,7 +115,7 @@ def issue_roofline(config: str, default_path: bool, measured_ms: float):
             "transcendental_per_launch": trans, "fma_mul_add_per_launch": fma, "floor_ms_lower": 1e3 * lower, "floor_ms_by_class": 1e3 * by_class,
             "kernel_ms_rocprof": kernel_ms, "frac_lower": 1e3 * lower / kernel_ms, "frac_by_class": 1e3 * by_class / kernel_ms,
             "cycles_per_valu_instruction_per_simd": cycles * N_SIMD / valu, "shader_cycles_per_launch": cycles, "class_cycles": ISSUE_CYCLES,
-            "source": f"profiles/{PROFILE_ROUND}/sq_issue_{config}.json (committed rocprofv3 --pmc passes of this command; NOT measured in this "
+            "source": f"profiles/{prof['_round']}/sq_issue_{config}.json (committed rocprofv3 --pmc passes of this command; NOT measured in this "
                       f"run; class costs: builder-calibrated micro-benchmarks, profiles/r01/valu_instruction_classes.txt)"}
 
 
@@ -175,6 +183,77 @@ def cpu_baseline(batch, H, W, min_seconds=10.0, max_views=None):
             "all_threads_inside_each_view": {"value": n2 / el2, "unit": "views/s", "cores": cores,
                                              "sample": f"up to {min(8, len(views))} views one after another, {cores} OpenMP threads inside each, {el2:.1f} s = {n2} renders "
                                                        "(the rounds 1-2 form: fork / join dominated at P = 128)"}}
+
+
+def consumed_roofline(dom, Rc, tiles, HW, NV, avg_ms):
+    """The tile kernel's scope priced on the instances the tiles actually CONSUME (R_c) instead of all R = sum of tiles touched."""
+    per_inst = {"render_fb": 116.0, "render_fwd": 40.0, "render_bwd": 76.0}[dom]
+    per_pix = {"render_fb": 48.0, "render_fwd": 24.0, "render_bwd": 24.0}[dom]
+    by_c = (per_inst * Rc + (8.0 * tiles if dom != "render_bwd" else 0.0) + per_pix * HW) * NV
+    return per_inst, by_c, by_c / 1e9 / (avg_ms / 1e3)
+
+
+def other_config_region(name, compact, rank, dev, steps=30, warmup=5):
+    """The hot-only step (the contractual region's definition: activations -> batched render -> loss -> backward -> dL/d head_out,
+    seeded by a plain loss.backward()) of ANOTHER BASELINE config, timed in the default driver run so that the scene-level figures
+    (BASELINE configs[2..4]; `--compact`: SURVEY 8d's secondary regime) are driver-observed, not builder-printed.  ~1-2 s each."""
+    from unipre3d_amd.fused import render_loss_fused
+    cfg = synthetic.CONFIGS[name]
+    B, P, V, H, W, level = cfg["B"], cfg["P"], cfg["V"], cfg["H"], cfg["W"], cfg["level"]
+    batch = synthetic.make_batch(B, P, V, H, W, level=level, seed=42 + rank, compact=compact).to(dev)
+    loss_kind = "focal_l2" if level == "object" else "l2"
+    head_out = batch.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+
+    def hot():
+        head_out.grad = None
+        loss, _, _ = render_loss_fused(head_out, batch.center, batch.world_view, batch.full_proj, batch.camera_center, batch.gt, batch.bg,
+                                       batch.fov_deg, H, W, level=level, offset_scale=batch.offset_scale, loss_kind=loss_kind,
+                                       return_images=False)
+        loss.backward()
+        return loss.detach()
+
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.3:
+        for _ in range(10):
+            hot()
+        torch.cuda.synchronize()
+
+    def region(profile):
+        for _ in range(warmup):
+            hot()
+        torch.cuda.synchronize()
+        if profile:
+            _lib.profile_begin(8 * (steps + 2), ("render_fb",), stride=2)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            l = hot()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return el, (_lib.profile_end() if profile else None), l
+
+    el, prof, l = region(True)
+    reps = sorted(1e3 * region(False)[0] / steps for _ in range(3))
+    NV, tiles = B * V, ((W + 15) // 16) * ((H + 15) // 16)
+    out = {"ms_per_step": 1e3 * el / steps, "views_s": NV * steps / el, "steps": steps, "warmup": warmup, "repeat_min_ms": reps[0],
+           "repeat_median_ms": reps[1], "final_loss": float(l),
+           "workload": f"{name}{' compact' if compact else ''}: {level}-level, P={P}, {H}x{W}, B={B} x V={V} = {NV} renders/step, loss {loss_kind}"}
+    ms, cnt = prof["render_fb"]
+    if cnt:
+        out["tile_kernel_ms"] = ms / cnt
+        out["tile_kernel_what"] = "HIP events on the launch stream around render_fb_wave_kernel + its bwd_reduce (every 2nd launch)"
+    with torch.no_grad():
+        g_used = synthetic.gaussians_from_batch(batch)
+        R_mean, walk = _read_num_rendered(g_used, batch, H, W, math.tan(batch.fov_deg * math.pi / 360))
+    out["num_rendered_per_view"] = R_mean
+    out["walked_mean"] = walk["sorted_positions_walked_per_tile_mean"]
+    out["walked_max"] = walk["sorted_positions_walked_per_tile_max"]
+    Rc = walk.get("instances_consumed_per_view")
+    if cnt and Rc is not None:
+        _, by_c, ach = consumed_roofline("render_fb", Rc, tiles, H * W, NV, ms / cnt)
+        out["instances_consumed_per_view"] = Rc
+        out["frac_consumed"] = ach / HBM_PEAK_GBS
+        out["frac_contractual"] = algorithmic_bytes("render_fb", P, R_mean, tiles, H * W) * NV / 1e9 / (ms / cnt / 1e3) / HBM_PEAK_GBS
+    return out
 
 
 def e2e_region(a, batch, dev, world, rank, B, V, H, W, loss_kind, timed):
@@ -311,19 +390,48 @@ def per_view_region(batch, B, P, V, H, W, loss_kind, steps=5):
         host[0] += time.perf_counter() - t0
         return loss.detach()
 
-    for _ in range(2):
-        step_fn()
-    torch.cuda.synchronize()
-    host[0] = 0.0
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        l = step_fn()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    return {"ms_per_step": 1e3 * el / steps, "value": B * V * steps / el, "unit": "views/s", "host_issue_ms_per_step": 1e3 * host[0] / steps,
-            "operator_calls_per_step": 2 * B * V, "us_per_forward_backward_pair": 1e6 * el / steps / (B * V), "final_loss": float(l),
-            "what": "reference call pattern unchanged: render_predicted per object and view through the drop-in "
-                    "diff_gaussian_rasterization module (C++ autograd binding over the C-ABI), torch.stack, torch loss, loss.backward()"}
+    def run(n):
+        for _ in range(2):
+            step_fn()
+        torch.cuda.synchronize()
+        host[0] = 0.0
+        t0 = time.perf_counter()
+        for _ in range(n):
+            l = step_fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, host[0], l
+
+    el, host_el, l = run(steps)
+    out = {"ms_per_step": 1e3 * el / steps, "value": B * V * steps / el, "unit": "views/s", "host_issue_ms_per_step": 1e3 * host_el / steps,
+           "operator_calls_per_step": 2 * B * V, "us_per_forward_backward_pair": 1e6 * el / steps / (B * V), "final_loss": float(l),
+           "what": "reference call pattern unchanged: render_predicted per object and view through the drop-in "
+                   "diff_gaussian_rasterization module (C++ autograd binding over the C-ABI), torch.stack, torch loss, loss.backward()"}
+    # the control: the SAME loop with a NO-OP operator (same inputs / outputs / autograd node, allocations only, no kernel), i.e. what
+    # the wrapper around the operator costs by itself (slicing, zeros_like, SH concat, radii > 0, torch.stack, loss, autograd through
+    # all of them); the operator's share of the route is the difference
+    from unipre3d_amd import rasterizer as _rz
+
+    class _NullOp(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, *tensors):
+            ctx.shapes = [t.shape for t in tensors]
+            ctx.dev = tensors[0].device
+            return torch.empty(3, H, W, device=ctx.dev), torch.empty(P, dtype=torch.int32, device=ctx.dev)
+
+        @staticmethod
+        def backward(ctx, g, _):
+            return tuple(torch.empty(s, device=ctx.dev) for s in ctx.shapes)
+
+    prev = _rz.set_operator_override(lambda *tensors: _NullOp.apply(*tensors) + (None,))
+    try:
+        el0, host0, _ = run(steps)
+    finally:
+        _rz.set_operator_override(prev)
+    out.update({"noop_operator_ms": 1e3 * el0 / steps, "noop_operator_host_issue_ms": 1e3 * host0 / steps,
+                "operator_share_ms": 1e3 * (el - el0) / steps,
+                "noop_what": "the same loop with the operator replaced by an autograd node that only allocates its outputs and gradients: "
+                             "the wrapper's own launches; operator_share_ms = ms_per_step - noop_operator_ms"})
+    return out
 
 
 def main():
@@ -341,6 +449,7 @@ def main():
                     help="which timed region the contractual `value` / `ms_per_step` quote: 'hot' (default, the contract's definition: the "
                          "collective-free render-loss hot path) or 'train' (the end-to-end stand-in training step, which at N > 1 CONTAINS the "
                          "DDP all-reduce over RCCL -- use it at every N of a scaling series to get the curve of the step with the exchange in it)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the hot-only steps of C3 / C4 / C5 / C2-compact (`other_configs`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     a = ap.parse_args()
@@ -524,15 +633,14 @@ def main():
             # contractual figure exceeds the peak at C3-C5 for ANY early-terminating implementation; this one cannot
             Rc = walk_stats.get("instances_consumed_per_view")
             if Rc is not None and dom in ("render_fb", "render_fwd", "render_bwd"):
-                per_inst = {"render_fb": 116.0, "render_fwd": 40.0, "render_bwd": 76.0}[dom]
-                per_pix = {"render_fb": 48.0, "render_fwd": 24.0, "render_bwd": 24.0}[dom]
-                by_c = (per_inst * Rc + (8.0 * tiles if dom != "render_bwd" else 0.0) + per_pix * H * W) * NV
+                per_inst, by_c, ach_c = consumed_roofline(dom, Rc, tiles, H * W, NV, kernels[dom]["avg_ms"])
                 out["roofline"]["consumed_bytes_per_launch"] = by_c
-                out["roofline"]["achieved_consumed"] = by_c / 1e9 / (kernels[dom]["avg_ms"] / 1e3)
-                out["roofline"]["frac_consumed"] = by_c / 1e9 / (kernels[dom]["avg_ms"] / 1e3) / HBM_PEAK_GBS
+                out["roofline"]["achieved_consumed"] = ach_c
+                out["roofline"]["frac_consumed"] = ach_c / HBM_PEAK_GBS
                 out["roofline"]["frac_consumed_what"] = (f"{per_inst:.0f} B x instances consumed ({Rc:.0f} per view) + per-tile / per-pixel terms of SURVEY 8d, "
                                                          "over the same live duration: an upper bound no early-terminating implementation can exceed 1 on")
-            out["roofline"]["traffic_source"] = (f"profiles/{PROFILE_ROUND}/pmc_traffic_{prof_cfg}.json (committed rocprofv3 --pmc passes of this command; "
+            _tp = _profile_json(f"pmc_traffic_{prof_cfg}.json")
+            out["roofline"]["traffic_source"] = (f"profiles/{_tp['_round']}/pmc_traffic_{prof_cfg}.json (committed rocprofv3 --pmc passes of this command; "
                                                  "NOT measured in this run)") if out["roofline"]["traffic"] else None
             tr = out["roofline"]["traffic"]
             if tr:
@@ -561,6 +669,20 @@ def main():
             out["forward_rasterizer"] = {"kernel": "render_fwd", "avg_ms": ms, "algorithmic_GB_per_launch": by / 1e9,
                                          "achieved_GBs": by / 1e9 / (ms / 1e3), "frac_of_8TBs": by / 1e9 / (ms / 1e3) / HBM_PEAK_GBS,
                                          "what": "operator forward (u3d_rasterize_forward) alone: colour, inverse depth and the backward's state written to HBM"}
+            # the same duration priced on the bytes this forward REALLY moves: PMC HBM bytes of the kernel from the
+            # committed pass when there is one, else the per-pixel outputs it must write (colour 12 + final_T 4 + limit 4 + inverse depth 4)
+            fp = _profile_json(f"pmc_traffic_fwd_{prof_cfg}.json") if default_path else None
+            real = None
+            if fp:
+                real = next((v["hbm_bytes_corrected"] for k, v in fp["per_launch"].items() if "render_fwd" in k), None)
+            src_real = f"profiles/{fp['_round'] if fp else PROFILE_ROUND}/pmc_traffic_fwd_{prof_cfg}.json (committed rocprofv3 --pmc passes; NOT measured in this run)"
+            if real is None:
+                real, src_real = 24.0 * H * W * NV, "analytic: the 24 B per pixel of outputs the kernel writes (no PMC pass committed for this run's shape)"
+            out["forward_rasterizer"].update({"real_bytes_per_launch": real, "frac_pmc_bytes": real / 1e9 / (ms / 1e3) / HBM_PEAK_GBS,
+                                              "real_bytes_source": src_real,
+                                              "reading": "frac_of_8TBs prices SURVEY 8(d)'s algorithmic bytes (40 R + 8 T + 24 HW per view: the contract's "
+                                                         "definition, what the >= 40 % target is quoted on); frac_pmc_bytes prices the bytes that really cross "
+                                                         "HBM -- this design never materialises the per-instance lists, so it moves ~4 x fewer"})
         elif fwd_err:
             out["forward_rasterizer"] = {"error": fwd_err}
         if not a.no_cpu_baseline and world == 1:
@@ -589,8 +711,11 @@ def main():
                 "scale_note": ("value = collective-free hot path (shards by object, no exchange); train_region_* = end-to-end stand-in step with the DDP "
                                "all-reduce of 117.9 MB + SyncBN over RCCL inside; n1_same_region = that step on one rank's batch before the DDP wrap, "
                                "same run") if ok else
-                              ("the region with the exchange did not complete" + (f": {e2e.get('error')}" if e2e.get("error") else "")
-                               + ("; skipped by flag" if (a.no_e2e or a.hot_only or level != "object") else ""))}
+                              ((f"the region with the exchange ran over backend '{e2e.get('collective_backend')}' with rccl_ranks = {e2e.get('rccl_ranks', 0)} "
+                                f"!= n_gpus = {world}: not an RCCL measurement (ranks sharing a device over gloo are a plumbing test)")
+                               if "value" in e2e else
+                               ("the region with the exchange did not complete" + (f": {e2e.get('error')}" if e2e.get("error") else "")
+                                + ("; skipped by flag" if (a.no_e2e or a.hot_only or level != "object") else "")))}
         return keys
 
     def on_budget():
@@ -670,6 +795,16 @@ def main():
             extras["train_step_e2e_standin"] = e2e_region(a, batch, dev, world, rank, B, V, H, W, loss_kind, timed)
         except Exception as e:  # noqa: BLE001
             extras["train_step_e2e_standin"] = {"error": repr(e)[:300]}
+    if world == 1 and a.config == "C2" and not (a.compact or a.unfused or a.two_pass or a.hot_only or a.no_other_configs):
+        # the other BASELINE configs' hot-only steps in the driver's own run
+        oc = {}
+        for key, (cname, comp) in (("C3", ("C3", False)), ("C4", ("C4", False)), ("C5", ("C5", False)), ("C2_compact", ("C2", True))):
+            try:
+                oc[key] = other_config_region(cname, comp, rank, dev)
+            except Exception as e:  # noqa: BLE001
+                oc[key] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+        extras["other_configs"] = oc
 
     watchdog.cancel()
     if rank == 0:

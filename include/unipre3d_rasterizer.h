@@ -41,7 +41,8 @@ extern "C" {
 /* flags (fields 11-13 of GaussianRasterizationSettings, gaussian_renderer/__init__.py:56-58) */
 #define U3D_FLAG_PREFILTERED 1   /* accepted, no effect: culled points are dropped either way */
 #define U3D_FLAG_ANTIALIASING 2  /* opacity *= sqrt(max(2.5e-5, det(cov)/det(cov+0.3 I))) */
-#define U3D_FLAG_DEBUG 4         /* synchronise + check after the launch sequence */
+#define U3D_FLAG_DEBUG 4         /* synchronise + check after the launch sequence (and validate item_offsets on the device first):
+                                    the call blocks on the stream, so it cannot be captured into a HIP graph */
 #define U3D_FLAG_EXACT_AA_GRAD 8 /* exact derivative of the anti-aliasing factor (DEV(vi)) */
 #define U3D_FLAG_STATS 16        /* also accumulate num_rendered[view] = sum of tiles touched (same-address atomics:
                                     ~12 ns each, 0.25 ms at 1.6 M Gaussian-views -- statistics only, off by default) */

@@ -631,6 +631,118 @@ def test_gradclip_deferred_drives_fused_adamw_without_a_host_read():
             assert all(torch.equal(x, y) for x, y in zip(b[0], b[1]))
 
 
+@pytest.mark.parametrize("case", ["mixed_clip", "mixed_small", "mixed_nan_in_bf16", "only_odd"])
+def test_gradclip_accepts_any_dtype_and_layout_like_the_reference(case):
+    """The reference's check accepts any gradient (train_network.py:368-390); the pointer-table kernels take contiguous fp32 only.
+    A channels_last conv-weight gradient, a bf16 and an fp16 parameter ride along: their statistics are folded into the same
+    device-side state block and they are scaled by the same coefficient -- against clip_grad_norm_ on the same set."""
+    import math
+    from unipre3d_amd import gradcheck
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    s = 1e-4 if case == "mixed_small" else 1.0
+    mk = lambda *shape: (torch.randn(*shape, generator=g) * s).to(dev)
+    grads = [] if case == "only_odd" else [mk(384, 128), mk(70001)]
+    grads += [mk(16, 8, 3, 3).contiguous(memory_format=torch.channels_last), mk(256, 64).to(torch.bfloat16), mk(33).to(torch.float16),
+              mk(40, 50).t()]
+    assert not grads[-1].is_contiguous() and not grads[-4].is_contiguous()
+    if case == "mixed_nan_in_bf16":
+        grads[-3][3, 3] = float("nan")
+    before = [x.clone() for x in grads]
+    ps = [torch.nn.Parameter(torch.zeros_like(x)) for x in grads]
+    for p, x in zip(ps, grads):
+        p.grad = x
+    ref_ps = [torch.nn.Parameter(torch.zeros_like(x)) for x in before]
+    for p, x in zip(ref_ps, before):
+        p.grad = x.clone()
+    bad_ref = any(bool(torch.isnan(p.grad).any() or torch.isinf(p.grad).any()) for p in ref_ps)
+    if not bad_ref:
+        torch.nn.utils.clip_grad_norm_(ref_ps, max_norm=1.0)
+    st = gradcheck.gradient_state(ps, 1.0)
+    ok = gradcheck.check_and_clip_gradients(ps, 1.0)
+    torch.cuda.synchronize()
+    assert ok == (not bad_ref) and st["found_inf"] == bad_ref
+    if bad_ref:
+        nn = lambda x: x.float().nan_to_num(7.0, 8.0, 9.0)
+        assert all(torch.equal(nn(p.grad), nn(b)) for p, b in zip(ps, before))
+        return
+    tot_ref = math.sqrt(sum(float((b.double() ** 2).sum()) for b in before))
+    assert abs(st["total_norm"] - tot_ref) <= 1e-9 * max(tot_ref, 1.0)
+    assert (st["coef"] == 1.0) == (case == "mixed_small")
+    for p, r in zip(ps, ref_ps):
+        assert p.grad.dtype == r.grad.dtype and p.grad.stride() == r.grad.stride()
+        tol = 1e-6 if p.grad.dtype == torch.float32 else 2e-2          # (half-precision gradients round after the multiply)
+        assert rel_l2(p.grad.float().cpu().numpy(), r.grad.float().cpu().numpy()) < tol
+    # the host-read-free route on the same set
+    for p, x in zip(ps, before):
+        p.grad = x.clone()
+    opt = torch.optim.AdamW([p for p in ps if p.dtype == torch.float32 and p.grad.is_contiguous()] or [torch.nn.Parameter(torch.zeros(1, device=dev))],
+                            lr=0.0, fused=True)
+    gradcheck.check_and_clip_deferred(ps, opt, 1.0)
+    torch.cuda.synchronize()
+    assert float(opt.found_inf) == 0.0
+    for p, r in zip(ps, ref_ps):
+        tol = 1e-6 if p.grad.dtype == torch.float32 else 2e-2
+        assert rel_l2(p.grad.float().cpu().numpy(), r.grad.float().cpu().numpy()) < tol
+
+
+def test_train_step_does_not_leave_a_stale_found_inf_on_the_optimizer():
+    """The deferred clip hands AdamW(fused=True) a device-side found_inf; train_step takes it off again after the step, so a later
+    step that does not clip (clip_grad=None) is not silently skipped, and return_found_inf exposes the decision to the caller."""
+    from unipre3d_amd import dp, step as step_mod
+    dev = torch.device("cuda:0")
+    _, b = _batch(2, 128, 2, 64, 64, level="object", seed=13)
+    torch.manual_seed(0)
+    model = dp.GaussianHead(32, 64).to(dev)
+    feats = torch.randn(2, 128, 32, generator=torch.Generator().manual_seed(2)).to(dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+    _, f0 = step_mod.train_step(model, feats, b, opt, 64, 64, 0, "focal_l2", fused=True, return_found_inf=True)
+    assert float(f0) == 0.0 and getattr(opt, "found_inf", None) is None and getattr(opt, "grad_scale", None) is None
+    bad = feats.clone(); bad[0, 0, 0] = float("nan")
+    w0 = [p.detach().clone() for p in model.parameters()]
+    _, f1 = step_mod.train_step(model, bad, b, opt, 64, 64, 0, "focal_l2", fused=True, return_found_inf=True)
+    assert float(f1) == 1.0 and all(torch.equal(x, p.detach()) for x, p in zip(w0, model.parameters()))      # skipped
+    assert getattr(opt, "found_inf", None) is None
+    step_mod.train_step(model, feats, b, opt, 64, 64, 0, "focal_l2", fused=True, clip_grad=None)               # no clip: must still step
+    assert any(not torch.equal(x, p.detach()) for x, p in zip(w0, model.parameters()))
+
+
+class _DropGrad(torch.autograd.Function):
+    """y = x; hands NO gradient back (None): the node upstream is then run with an undefined grad_output."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return None
+
+
+def test_fused_step_backward_after_an_unused_loss_recomputes():
+    """A retained node whose first backward arrived with an UNDEFINED gradient for the loss released its lease on the backward
+    scratch; a later backward through the same node must recompute the forward half instead of reading a buffer that another
+    forward has reused in the meantime."""
+    from unipre3d_amd import fused
+    _, b = _batch(2, 128, 2, 64, 64, level="object", seed=17)
+    h = b.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+    args = (b.center, b.world_view, b.full_proj, b.camera_center, b.gt, b.bg, b.fov_deg, 64, 64)
+    ref_loss, _, _ = fused.render_loss_fused(h, *args, level="object", return_images=False)
+    ref_loss.backward()
+    g_ref = h.grad.clone(); h.grad = None
+    loss, _, _ = fused.render_loss_fused(h, *args, level="object", return_images=False)
+    _DropGrad.apply(loss).backward(retain_graph=True)                  # the step's node sees an undefined gradient
+    assert h.grad is None or not bool(h.grad.any())
+    h.grad = None
+    h2 = (h.detach() * 0.5).requires_grad_(True)                         # another forward takes over the released scratch ...
+    l2, _, _ = fused.render_loss_fused(h2, *args, level="object", return_images=False)
+    loss.backward()                                                     # ... before the retained node is backpropagated for real
+    l2.backward()
+    torch.cuda.synchronize()
+    assert rel_l2(h.grad.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6
+    assert bool(torch.isfinite(h2.grad).all()) and bool(h2.grad.any())
+
+
 def test_fused_step_is_capturable_in_a_hip_graph():
     """The fused step (render_loss_fused + loss.backward()) holds no host synchronisation and sizes everything from shapes, so it
     can be captured in a HIP graph (torch.cuda.CUDAGraph) and replayed on new head outputs copied into the static input: loss and

@@ -54,6 +54,7 @@ def test_bench_self_launches_two_ranks():
               "speedup_over_n1_same_region", "scale_ok"):
         assert k in out, k
     assert out["rccl_ranks"] == 0 and out["collective_backend"] == "gloo" and out["scale_ok"] is False
+    assert "gloo" in out["scale_note"] and "rccl_ranks = 0" in out["scale_note"]          # ... and the line says why
     assert out["train_region_value"] == e2e["value"] and out["n1_same_region"] == e2e["n1_same_region"]["value"]
     assert out["gradient_bytes_all_reduced_per_step"] == 4 * 29_464_215 and out["speedup_over_n1_same_region"] > 0
     # the same launch quoting the step WITH the exchange in it as `value`
@@ -79,3 +80,20 @@ def test_bench_under_torch_distributed_run():
     assert len(lines) == 1, res.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and "error" not in out["train_step_with_head"]
+
+
+def test_default_line_carries_the_other_configs_and_the_noop_control():
+    """The driver's own command (`python bench.py --gpus 1`, here with fewer steps): after the contractual C2 region the line
+    holds the hot-only steps of C3 / C4 / C5 / C2-compact (`other_configs`) and the per-view route's NO-OP-operator control."""
+    out = _run(["--steps", "10", "--warmup", "3", "--cpu-seconds", "1", "--no-e2e"])
+    oc = out["other_configs"]
+    for k in ("C3", "C4", "C5", "C2_compact"):
+        assert "error" not in oc[k], oc[k]
+        for f in ("ms_per_step", "views_s", "tile_kernel_ms", "frac_consumed", "walked_mean"):
+            assert oc[k][f] > 0, (k, f)
+        assert oc[k]["tile_kernel_ms"] < oc[k]["ms_per_step"] and 0 < oc[k]["frac_consumed"] < 1
+    pv = out["per_view_dropin"]
+    assert "error" not in pv, pv
+    assert pv["noop_operator_ms"] > 0 and abs(pv["operator_share_ms"] - (pv["ms_per_step"] - pv["noop_operator_ms"])) < 1e-9
+    fr = out["forward_rasterizer"]
+    assert 0 < fr["frac_pmc_bytes"] <= fr["frac_of_8TBs"]

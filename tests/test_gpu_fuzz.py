@@ -8,7 +8,7 @@ import torch
 from conftest import rel_l2
 from scenes import DIFF_KEYS, cotangents, scene, to_numpy
 from arbiter import assert_parity, head_grad_arbiter_all
-from test_gpu_parity import TOL, _run_gpu, near
+from test_gpu_parity import TOL, _run_gpu
 
 pytestmark = pytest.mark.gpu
 # the same allowance over the fp32 restatement's own distance as every other test (arbiter.GAP_K = 2; rounds 1-2 needed 4 here because
@@ -35,7 +35,8 @@ def test_fuzz_forward_backward_vs_oracle(oracle_mod, P, H, W, level, compact, de
     r32 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc))
     r64 = oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
     assert np.array_equal(radii, r32.radii)      # integer output: bit-exact against the fp32 restatement
-    assert near(color, r32.color, r64.color) and near(invd, r32.invdepth, r64.invdepth)
+    assert_parity(color, r32.color, r64.color, "color")
+    assert_parity(invd, r32.invdepth, r64.invdepth, "invd")
     g32 = oracle_mod.backward(r32, dcol.numpy(), dinv.numpy())
     g64 = oracle_mod.backward(r64, dcol.numpy().astype(np.float64), dinv.numpy().astype(np.float64))
     for k in DIFF_KEYS + ("means2D",):

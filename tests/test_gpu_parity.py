@@ -1,22 +1,19 @@
 """Parity proper: the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs.
-Tolerance (BASELINE.json north_star): 1e-4 relative L2 on images and gradients; radii are integers -> exact."""
+Tolerance (BASELINE.json north_star): 1e-4 relative L2 on images and gradients; radii are integers -> exact.  ONE rule for every
+comparison that brings both restatements (tests/arbiter.py::assert_parity): within 1e-4 of the fp64 arbiter, or within 2 x the
+fp32 restatement's own distance from it (capped at 10 x the tolerance; such passes are listed at the end of the session)."""
 import math
 
 import numpy as np
 import pytest
 import torch
 
+from arbiter import assert_parity
 from conftest import rel_l2
 from scenes import DIFF_KEYS, SMALL_CASES, cotangents, scene, to_numpy
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-
-
-def near(x, o32, o64):
-    """Parity criterion: within TOL of the fp32 restatement, or -- when the fp32 restatement itself sits on the other
-    side of a discrete threshold (alpha < 1/255, T < 1e-4, ceil(radius)) from the fp64 arbiter -- of the fp64 one."""
-    return min(rel_l2(x, o32), rel_l2(x, o64)) < TOL
 
 
 def _settings(sc, t, debug=True, antialiasing=True):
@@ -108,10 +105,11 @@ def test_radix_sort_far_depths(oracle_mod, F, P):
     r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
     zv = (np.c_[to_numpy(sc)["means3D"].astype(np.float64), np.ones(P)] @ V2.numpy())[:, 2]
     assert zv[r.radii > 0].min() > 0.2 * F and zv[r.radii > 0].max() > 4.0 * zv[r.radii > 0].min()
-    assert np.array_equal(radii, r.radii) and near(color, r.color, r64.color)
+    assert np.array_equal(radii, r.radii)
+    assert_parity(color, r.color, r64.color, "color")
     go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
     for k in DIFF_KEYS:
-        assert near(g[k].reshape(go[k].shape), go[k], go64[k]), k
+        assert_parity(g[k].reshape(go[k].shape), go[k], go64[k], f"{k}")
 
 
 @pytest.mark.parametrize("n_dense,spread", [(50, 1e-3), (200, 1e-3), (800, 1e-3), (3000, 1e-3), (900, 1e-7), (1500, 0.0)])
@@ -135,10 +133,11 @@ def test_large_P_sort_dense_depth_bucket(oracle_mod, n_dense, spread):
     dcol, dinv = cotangents(H, W)
     color, invd, radii, gg = _run_gpu(sc, dcol, dinv)
     r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
-    assert np.array_equal(radii, r.radii) and near(color, r.color, r64.color)
+    assert np.array_equal(radii, r.radii)
+    assert_parity(color, r.color, r64.color, "color")
     go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
     for k in DIFF_KEYS:
-        assert near(gg[k].reshape(go[k].shape), go[k], go64[k]), k
+        assert_parity(gg[k].reshape(go[k].shape), go[k], go64[k], f"{k}")
 
 
 @pytest.mark.parametrize("n_tied", [100, 700])
@@ -157,10 +156,11 @@ def test_block_sort_clustered_depths(oracle_mod, n_tied):
     dcol, dinv = cotangents(H, W)
     color, invd, radii, gg = _run_gpu(sc, dcol, dinv)
     r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
-    assert np.array_equal(radii, r.radii) and near(color, r.color, r64.color)
+    assert np.array_equal(radii, r.radii)
+    assert_parity(color, r.color, r64.color, "color")
     go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
     for k in DIFF_KEYS:
-        assert near(gg[k].reshape(go[k].shape), go[k], go64[k]), k
+        assert_parity(gg[k].reshape(go[k].shape), go[k], go64[k], f"{k}")
 
 
 def test_depth_ties_small_P(oracle_mod):
@@ -233,9 +233,10 @@ def test_non_saturating_pixels_scan_whole_list(oracle_mod):
         r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
         go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
         assert int(r.n_contrib.max()) > 256
-        assert np.array_equal(radii, r.radii) and near(color, r.color, r64.color)
+        assert np.array_equal(radii, r.radii)
+        assert_parity(color, r.color, r64.color, "color")
         for k in DIFF_KEYS:
-            assert near(g[k].reshape(go[k].shape), go[k], go64[k]), k
+            assert_parity(g[k].reshape(go[k].shape), go[k], go64[k], f"{k}")
 
 
 @pytest.mark.parametrize("P,H,W,level", [(2000, 128, 128, "object"), (6000, 120, 160, "scene")])
@@ -257,10 +258,12 @@ def test_truly_compact_splats_operator_level(oracle_mod, P, H, W, level):
     vis = int((r.radii > 0).sum())
     assert vis > P // 10 and r.num_rendered < 0.25 * vis * tiles         # genuinely sparse binning
     assert int(r.n_contrib.max()) > (64 if level == "object" else 16)    # long per-tile lists (oracle counts per tile)
-    assert np.array_equal(radii, r.radii) and near(color, r.color, r64.color) and near(invd, r.invdepth, r64.invdepth)
+    assert np.array_equal(radii, r.radii)
+    assert_parity(color, r.color, r64.color, "color")
+    assert_parity(invd, r.invdepth, r64.invdepth, "invd")
     go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
     for k in DIFF_KEYS + ("means2D",):
-        assert near(gr[k].reshape(go[k].shape), go[k], go64[k]), k
+        assert_parity(gr[k].reshape(go[k].shape), go[k], go64[k], f"{k}")
 
 
 def _tile_flags(sc):
@@ -334,9 +337,11 @@ def test_loop_variants_high_opacity(oracle_mod, P, fade, every):
     color, invd, radii, g = _run_gpu(sc, dcol, dinv)
     r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
     go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
-    assert np.array_equal(radii, r.radii) and near(color, r.color, r64.color) and near(invd, r.invdepth, r64.invdepth)
+    assert np.array_equal(radii, r.radii)
+    assert_parity(color, r.color, r64.color, "color")
+    assert_parity(invd, r.invdepth, r64.invdepth, "invd")
     for k in DIFF_KEYS + ("means2D",):
-        assert near(g[k].reshape(go[k].shape), go[k], go64[k]), k
+        assert_parity(g[k].reshape(go[k].shape), go[k], go64[k], f"{k}")
 
 
 def test_loop_variant_selection(oracle_mod):

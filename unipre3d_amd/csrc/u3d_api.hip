@@ -118,22 +118,25 @@ U3DLoss make_loss(const u3d_raster_desc& d, const u3d_loss_desc& l, const float*
 // checked before anything is launched: first 0, non-decreasing, no set larger than desc.P, last == total_P.  (Without the flag a
 // set that claims more than desc.P Gaussians is truncated to desc.P by u3d_set_span -- its tail is never projected -- instead
 // of indexing the sort's LDS keys out of bounds; the host bindings derive P and the prefix sums from the sets' sizes themselves.)
-__device__ int g_offsets_bad;
-__global__ void validate_offsets_kernel(const int32_t* __restrict__ off, int n_items, int P, int total_P) {
+// The verdict travels through a word of the CALLER's scratch (the first 4 bytes of `geom`, which nothing has written yet at this
+// point of a forward call), so two streams / threads / devices validating at once never share state.  The check synchronises the
+// stream: a U3D_FLAG_DEBUG call cannot be captured into a HIP graph.
+__global__ void validate_offsets_kernel(const int32_t* __restrict__ off, int n_items, int P, int total_P, int* __restrict__ flag) {
   int bad = 0;
   for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
     const int a = off[i], b = off[i + 1];
     if (b < a || b - a > P || a < 0 || b > total_P) bad = 1;
   }
   if (threadIdx.x == 0 && (off[0] != 0 || off[n_items] != total_P)) bad = 1;
-  if (bad) g_offsets_bad = 1;
+  if (bad) *flag = 1;
 }
-int validate_offsets(const u3d_raster_desc& d, hipStream_t s) {
+int validate_offsets(const u3d_raster_desc& d, void* scratch_word, hipStream_t s) {
   if (d.total_P <= 0 || !(d.flags & U3D_FLAG_DEBUG)) return U3D_OK;
+  if (!scratch_word) return U3D_ERR_INVALID_ARGUMENT;
   int bad = 0;
-  if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_offsets_bad), &bad, sizeof(int), 0, hipMemcpyHostToDevice, s) != hipSuccess) return U3D_ERR_LAUNCH;
-  hipLaunchKernelGGL(validate_offsets_kernel, dim3(1), dim3(256), 0, s, d.item_offsets, d.n_items, d.P, d.total_P);
-  if (hipMemcpyFromSymbolAsync(&bad, HIP_SYMBOL(g_offsets_bad), sizeof(int), 0, hipMemcpyDeviceToHost, s) != hipSuccess) return U3D_ERR_LAUNCH;
+  if (hipMemsetAsync(scratch_word, 0, sizeof(int), s) != hipSuccess) return U3D_ERR_LAUNCH;
+  hipLaunchKernelGGL(validate_offsets_kernel, dim3(1), dim3(256), 0, s, d.item_offsets, d.n_items, d.P, d.total_P, (int*)scratch_word);
+  if (hipMemcpyAsync(&bad, scratch_word, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return U3D_ERR_LAUNCH;
   if (hipStreamSynchronize(s) != hipSuccess) return U3D_ERR_LAUNCH;
   return bad ? U3D_ERR_INVALID_ARGUMENT : U3D_OK;
 }
@@ -204,7 +207,7 @@ int u3d_rasterize_forward(const u3d_raster_desc* desc, const float* bg, const fl
     if (shs && d.sh_coeffs < (d.sh_degree + 1) * (d.sh_degree + 1)) return U3D_ERR_INVALID_ARGUMENT;
   }
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = validate_offsets(d, s)) != U3D_OK) return rc;
+  if ((rc = validate_offsets(d, geom, s)) != U3D_OK) return rc;
   U3DBuffers b{};
   u3d_carve(d, geom, binning, image, &b);
   if (d.flags & U3D_FLAG_STATS) (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
@@ -288,7 +291,7 @@ int u3d_render_loss_forward(const u3d_raster_desc* desc, const u3d_head_desc* he
       !geom || !binning || !image || !fused)
     return U3D_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = validate_offsets(d, s)) != U3D_OK) return rc;
+  if ((rc = validate_offsets(d, geom, s)) != U3D_OK) return rc;
   U3DBuffers b{};
   u3d_carve(d, geom, binning, image, &b);
   U3DFused f{};
@@ -374,7 +377,7 @@ int u3d_render_loss_step_forward(const u3d_raster_desc* desc, const u3d_head_des
       !fused || !backward_scratch)
     return U3D_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = validate_offsets(d, s)) != U3D_OK) return rc;
+  if ((rc = validate_offsets(d, geom, s)) != U3D_OK) return rc;
   U3DBuffers b{};
   const U3DLayout Lay = u3d_carve(d, geom, binning, nullptr, &b);
   U3DFused f{};

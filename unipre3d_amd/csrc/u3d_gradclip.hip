@@ -31,8 +31,9 @@ struct Acc {
   uint32_t bad = 0u;
   __device__ __forceinline__ void add(float x) {
     const float a = fabsf(x);
-    bad |= !(a <= 3.402823466e38f);   // NaN and +-Inf both fail the comparison (train_network.py:377: isnan(...) or isinf(...))
-    m = fmaxf(m, a);                    // (fmaxf drops NaN: the flag carries it)
+    const bool fin = a <= 3.402823466e38f;   // NaN and +-Inf both fail the comparison (train_network.py:377: isnan(...) or isinf(...))
+    bad |= !fin;
+    m = fmaxf(m, fin ? a : 0.f);        // largest FINITE |g| (the flag carries the rest)
     s += (double)x * (double)x;         // f64: a finite fp32 gradient cannot overflow the sum of squares
   }
 };

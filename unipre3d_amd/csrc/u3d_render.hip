@@ -529,6 +529,9 @@ static_assert(TILE_WAVES == 1, "one wave = one workgroup = one tile");
   const TileGeom G{sorted_id, sorted_rect, xy, conic_op, rgbd, vb_, tx, ty, rect_indirect, touched, touched_words, touched_words ? u3d_view_gbase(span, view) : 0}
 
 // ---- forward (operator path): colour, inverse depth, and the state the backward kernel restarts from --------
+// DEPTH = false: the caller drops the inverse-depth output (the reference does: `rendered_image, radii, _ = rasterizer(...)`,
+// gaussian_renderer/__init__.py:89) -- no 1/depth staging, one FMA less per pixel and Gaussian, 4 B less per pixel written.
+template <bool DEPTH>
 __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
     U3DSpan span, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, const uint32_t* __restrict__ sorted_id,
     const uint2* __restrict__ sorted_rect, int rect_indirect, const uint32_t* __restrict__ n_vis, const float2* __restrict__ xy,
@@ -539,13 +542,13 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
   uint32_t* const touched_words = nullptr;
   __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
-  __shared__ float sD[TILE_WAVES][U3D_WAVE];
+  __shared__ float sD[TILE_WAVES][DEPTH ? U3D_WAVE : 1];
   U3D_TILE_PROLOGUE(TILE_WAVES);
   const TileLds L{sP0[wave], sP1[wave], sP2[wave], sD[wave], nullptr};
   TileFwd F;
   const uint32_t nv = n_vis[view];
-  const bool plain = tile_forward<true, true>(L, G, lane, nv, pyf, pxf, inside, F);
-  if (!plain) tile_forward<true, false>(L, G, lane, nv, pyf, pxf, inside, F);
+  const bool plain = tile_forward<DEPTH, true>(L, G, lane, nv, pyf, pxf, inside, F);
+  if (!plain) tile_forward<DEPTH, false>(L, G, lane, nv, pyf, pxf, inside, F);
 
   float o0[4], o1[4], o2[4], lim[4];
 #pragma unroll
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
   store4(out_color + cid0, vec, inside, o0);
   store4(out_color + cid0 + npix, vec, inside, o1);
   store4(out_color + cid0 + 2 * npix, vec, inside, o2);
-  if (out_invdepth) store4(out_invdepth + pid0, vec, inside, F.Dv);
+  if (DEPTH) store4(out_invdepth + pid0, vec, inside, F.Dv);
   if (lane == 0) tile_last[lid] = F.wlast | (plain ? U3D_TILE_PLAIN_BIT : 0u);   // the backward kernel takes the same loop variant
   if (loss.kind != 0) {
     float g0[4], g1[4], g2[4], e = 0.f;
@@ -971,7 +974,8 @@ void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   const uint32_t ntiles = (uint32_t)(d.n_items * d.views_per_item * T);
   if (ntiles == 0) return;
   const TileGrid tg = tile_grid(d, tiles_x, T);
-  hipLaunchKernelGGL(render_fwd_wave_kernel, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height, d.image_width,
+  auto* kern = out_invdepth ? render_fwd_wave_kernel<true> : render_fwd_wave_kernel<false>;
+  hipLaunchKernelGGL(kern, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height, d.image_width,
                      tiles_x, T, ntiles, tg.magic, b.sorted_id, u3d_rect_indirect(d) ? b.rect : b.sorted_rect, u3d_rect_indirect(d), b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
                      out_invdepth, b.final_T, b.n_contrib, b.tile_last, loss);
 }

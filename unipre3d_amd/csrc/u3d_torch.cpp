@@ -363,6 +363,9 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
     variable_list out(22);
     if (!grads[0].defined()) {                 // the loss was not used downstream: nothing to chain, and the accumulators stay dirty
       workspace_release(key, ticket, shape_key, false);
+      // the lease is gone (another forward may reuse the buffer): a later backward through this retained node must not read it,
+      // it recomputes the forward half into a fresh lease like any second backward does
+      ctx->saved_data["consumed"] = true;
       out[0] = at::zeros_like(head_out);
       return out;
     }
@@ -374,8 +377,9 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
     const char* base = (const char*)arena.data_ptr();
     if (ctx->saved_data["consumed"].toBool()) {
       // backward(retain_graph=True) followed by another backward: the first one consumed (and re-zeroed) the accumulators, so the
-      // forward half is run again into a fresh lease -- same inputs, same arena, identical results; the rare path pays a recompute,
-      // the hot path keeps nothing alive for it
+      // forward half is run again into a fresh lease -- same inputs, same arena, identical results; the rare path pays a recompute.
+      // (What the node DOES pin from forward to backward: the forward arena, the leased backward scratch, gt and bg -- see
+      // INTEGRATION.md "memory held between forward and backward".)
       const auto lv = ctx->saved_data["loss"].toDoubleVector();
       u3d_loss_desc ld{(int32_t)lv[0], (float)lv[1], (float)lv[2]};
       const Lease lease = workspace_acquire(key, plan, shape_key, at::TensorOptions().dtype(at::kByte).device(dev));

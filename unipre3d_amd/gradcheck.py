@@ -10,6 +10,9 @@ over a device table of gradient pointers (per-chunk f64 sum of squares, max-abs,
 finalize, ONE 32-byte host read, and -- only when the norm exceeds max_norm -- one multi-tensor scale launch.
 `check_and_clip_deferred` is the same without any host read: the flag and the coefficient stay on the device as the
 `found_inf` / `grad_scale` scalars torch's fused AdamW consumes.  No fallback on a HIP device: a missing library raises.
+Gradients the pointer-table kernels cannot take (not fp32, not contiguous -- channels_last --, or on another device) are
+accepted like the reference accepts them: their statistics are computed with torch ops ON THE DEVICE and folded into the same
+state block as one more partial record, and they are scaled by the same device-side coefficient.
 
 CPU tensors (the world-size-2 gloo tests of the DP harness run the training step on the host) take the multi-tensor torch
 formulation below; it is host logic, not the product path.
@@ -63,13 +66,14 @@ class _Table:
         self.n_chunks = acc
         n = self.n
         host = torch.empty(2 * n + (n + 2) // 2, dtype=torch.int64, pin_memory=True)     # ptrs | numel | first (int32 pairs)
-        host[:n] = torch.tensor([p for p, _ in key], dtype=torch.int64)
-        host[n:2 * n] = torch.tensor([ne for _, ne in key], dtype=torch.int64)
+        if n:
+            host[:n] = torch.tensor([p for p, _ in key], dtype=torch.int64)
+            host[n:2 * n] = torch.tensor([ne for _, ne in key], dtype=torch.int64)
         host[2 * n:].view(torch.int32)[:n + 1] = torch.tensor(first, dtype=torch.int32)
         self.host = host                                       # (pinned, kept alive: the upload is asynchronous on the current stream)
         self.buf = host.to(dev, non_blocking=True)
         self.ptrs, self.numel, self.first = self.buf[:n], self.buf[n:2 * n], self.buf[2 * n:]
-        self.partials = torch.empty(max(self.n_chunks, 1) * 2, dtype=torch.float64, device=dev)   # 16 B per chunk
+        self.partials = torch.empty((self.n_chunks + 1) * 2, dtype=torch.float64, device=dev)     # 16 B per chunk + one spare record
         self.state = torch.zeros(4, dtype=torch.float64, device=dev)                              # 32 B, see the header
 
 
@@ -93,26 +97,70 @@ def _device_grads(parameters):
     return grads
 
 
+def _split(grads):
+    """(device of the set, the gradients the multi-tensor kernels take, the rest).  The kernels read contiguous fp32 tensors on
+    ONE device through a pointer table; anything else -- a channels_last conv weight gradient, a bf16 / fp16 parameter, a shard on
+    another device -- is handled like the reference handles every gradient (train_network.py:368-390 accepts any dtype / layout):
+    with torch ops, folded into the same state block as one extra partial record."""
+    dev = next((g.device for g in grads if g.device.type == "cuda"), grads[0].device)
+    fast, rest = [], []
+    for g in grads:
+        (fast if (g.dtype == torch.float32 and g.is_contiguous() and g.device == dev) else rest).append(g)
+    return dev, fast, rest
+
+
+def _rest_record(rest, dev, partials, slot):
+    """Statistics of the gradients the kernels cannot take, written on the device (no host read) into partial record `slot`
+    (double sum of squares | float max finite |g| | uint32 non-finite flag, include/unipre3d_gradclip.h)."""
+    sumsq = torch.zeros((), dtype=torch.float64, device=dev)
+    amax = torch.zeros((), dtype=torch.float32, device=dev)
+    bad = torch.zeros((), dtype=torch.bool, device=dev)
+    for g in rest:
+        gd = g.detach()
+        fin = torch.isfinite(gd)
+        sumsq = sumsq + gd.double().pow(2).sum().to(dev)
+        amax = torch.maximum(amax, torch.where(fin, gd.abs(), torch.zeros((), dtype=gd.dtype, device=gd.device)).max().float().to(dev))
+        bad = bad | (~fin.all()).to(dev)
+    partials[2 * slot] = sumsq
+    rec = partials[2 * slot + 1: 2 * slot + 2]
+    rec.view(torch.float32)[0] = amax
+    rec.view(torch.int32)[1] = bad.to(torch.int32)
+
+
+def _scale_rest(rest, t):
+    """g *= coef for the gradients outside the pointer table; coef is 1 on the device when nothing is to be clipped or a
+    non-finite value was found (so the values stay untouched, like the kernel's early exit)."""
+    coef = t.state.view(torch.float32)[4]
+    for g in rest:
+        g.mul_(coef.to(device=g.device))
+
+
 def _launch_stats(grads, max_norm):
     from .rasterizer import _stream_ptr
-    dev = grads[0].device
-    for g in grads:
-        if g.dtype != torch.float32 or not g.is_contiguous() or g.device != dev:
-            raise TypeError("unipre3d_amd.gradcheck: gradients must be contiguous fp32 tensors on one HIP device "
-                            f"(got {g.dtype}, contiguous={g.is_contiguous()}, {g.device})")
-    lib, t, s = load(), _table_for(grads, dev), _stream_ptr(dev)
-    rc = lib.u3d_gradclip_stats(t.ptrs.data_ptr(), t.numel.data_ptr(), t.first.data_ptr(), t.n, t.n_chunks, t.partials.data_ptr(), s)
+    dev, fast, rest = _split(grads)
+    if dev.type != "cuda":
+        raise RuntimeError("unipre3d_amd.gradcheck: the HIP path needs gradients on a HIP device")
+    lib, t, s = load(), _table_for(fast, dev), _stream_ptr(dev)
+    rc = 0
+    if fast:
+        rc = lib.u3d_gradclip_stats(t.ptrs.data_ptr(), t.numel.data_ptr(), t.first.data_ptr(), t.n, t.n_chunks, t.partials.data_ptr(), s)
+    if rest:
+        _rest_record(rest, dev, t.partials, t.n_chunks)          # (the table keeps one spare record for them)
     if rc == 0:
-        rc = lib.u3d_gradclip_finalize(t.partials.data_ptr(), t.n_chunks, float(max_norm), t.state.data_ptr(), s)
+        rc = lib.u3d_gradclip_finalize(t.partials.data_ptr(), t.n_chunks + (1 if rest else 0), float(max_norm), t.state.data_ptr(), s)
     if rc != 0:
         raise RuntimeError(f"u3d_gradclip_stats / _finalize failed with code {rc}")
-    return lib, t, s
+    return lib, t, s, rest
 
 
-def _launch_scale(lib, t, s):
-    rc = lib.u3d_gradclip_scale(t.ptrs.data_ptr(), t.numel.data_ptr(), t.first.data_ptr(), t.n, t.n_chunks, t.state.data_ptr(), s)
+def _launch_scale(lib, t, s, rest=()):
+    rc = 0
+    if t.n:
+        rc = lib.u3d_gradclip_scale(t.ptrs.data_ptr(), t.numel.data_ptr(), t.first.data_ptr(), t.n, t.n_chunks, t.state.data_ptr(), s)
     if rc != 0:
         raise RuntimeError(f"u3d_gradclip_scale failed with code {rc}")
+    if rest:
+        _scale_rest(rest, t)
 
 
 def gradient_state(parameters: Iterable[torch.nn.Parameter], max_norm: float = 1.0) -> dict:
@@ -120,7 +168,7 @@ def gradient_state(parameters: Iterable[torch.nn.Parameter], max_norm: float = 1
     grads = _device_grads(parameters)
     if not grads:
         return {"total_norm": 0.0, "amax": 0.0, "coef": 1.0, "grad_scale": 1.0, "found_inf": False}
-    _, t, _ = _launch_stats(grads, max_norm)
+    _, t, _, _ = _launch_stats(grads, max_norm)
     total, amax, coef, gscale, found, _ = struct.unpack("ddffff", t.state.cpu().numpy().tobytes())
     return {"total_norm": total, "amax": amax, "coef": coef, "grad_scale": gscale, "found_inf": found != 0.0}
 
@@ -130,17 +178,17 @@ def check_and_clip_gradients(parameters: Iterable[torch.nn.Parameter], max_norm:
     grads = [p.grad for p in parameters if p.grad is not None]
     if not grads:
         return True
-    if grads[0].device.type != "cuda":
+    if not any(g.device.type == "cuda" for g in grads):
         return _check_and_clip_host(grads, max_norm)
     grads = [g for g in grads if g.numel() > 0]
     if not grads:
         return True
-    lib, t, s = _launch_stats(grads, max_norm)
+    lib, t, s, rest = _launch_stats(grads, max_norm)
     total, amax, coef, gscale, found, _ = struct.unpack("ddffff", t.state.cpu().numpy().tobytes())     # the single host sync
     if found != 0.0:
         return False
     if coef != 1.0:
-        _launch_scale(lib, t, s)
+        _launch_scale(lib, t, s, rest)
     return True
 
 
@@ -154,10 +202,10 @@ def check_and_clip_deferred(parameters: Iterable[torch.nn.Parameter], optimizer:
     grads = _device_grads(parameters)
     if not grads:
         return
-    if grads[0].device.type != "cuda":
+    if not any(g.device.type == "cuda" for g in grads):
         raise RuntimeError("check_and_clip_deferred needs gradients on a HIP device (and a fused optimizer)")
-    lib, t, s = _launch_stats(grads, max_norm)
-    _launch_scale(lib, t, s)                                   # reads coef / found_inf on the device
+    lib, t, s, rest = _launch_stats(grads, max_norm)
+    _launch_scale(lib, t, s, rest)                             # reads coef / found_inf on the device
     f32 = t.state.view(torch.float32)
     optimizer.grad_scale = None                                # (already applied by the scale pass)
     optimizer.found_inf = f32[6]                               # (0-dim view into the state block)

@@ -105,7 +105,10 @@ def ragged_layout(sizes, device):
     sizes = tuple(int(n) for n in sizes)
     if not sizes or min(sizes) < 0 or max(sizes) <= 0:
         raise ValueError(f"ragged batch: set sizes must be non-negative with at least one non-empty set, got {sizes}")
-    key = (sizes, str(device))
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:          # a bare "cuda" means the CURRENT device: key on where the table lives
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (sizes, device.type, device.index)
     hit = _layout_cache.get(key)
     if hit is None:
         off = [0]
@@ -230,6 +233,19 @@ def split_ragged_radii(radii: torch.Tensor, sizes, V: int):
     return out
 
 
+# bench.py's control of the per-view route only: a callable taking the operator's differentiable tensor inputs and returning the
+# operator's 3-tuple WITHOUT launching anything (`per_view_dropin.noop_operator_ms`: what the loop around the operator costs by
+# itself).  None in every product path.
+_operator_override = None
+
+
+def set_operator_override(fn):
+    """Install (or, with None / the returned previous value, remove) the bench's NO-OP operator control; returns the previous one."""
+    global _operator_override
+    prev, _operator_override = _operator_override, fn
+    return prev
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()
@@ -253,5 +269,8 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if _operator_override is not None:
+            return _operator_override(*[t for t in (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+                                        if t is not None])
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings)

@@ -36,10 +36,13 @@ def render_loss_forward(raw: torch.Tensor, batch: SyntheticBatch, H: int, W: int
 
 def train_step(model: torch.nn.Module, feats: torch.Tensor, batch: SyntheticBatch, optimizer: torch.optim.Optimizer, H: int,
                W: int, input_images: int = 0, loss_kind: str = "focal_l2", render_fn: Optional[Callable] = None,
-               clip_grad: Optional[float] = 1.0, fused: bool = False) -> torch.Tensor:
+               clip_grad: Optional[float] = 1.0, fused: bool = False, return_found_inf: bool = False):
     """zero_grad -> head -> render-loss -> backward (DDP all-reduce inside) -> clip -> optimizer step
     (train_network.py:329-352 without the per-parameter NaN scan's host syncs).
-    fused=True: activations + batched render + loss run inside the HIP library (fused.render_loss_fused)."""
+    fused=True: activations + batched render + loss run inside the HIP library (fused.render_loss_fused).
+    return_found_inf=True: returns (loss, found_inf) where found_inf says whether the step was SKIPPED because a gradient held a
+    NaN / Inf -- a bool on the host-read route, a 0-dim device tensor (1.0 = skipped; no host sync) on the deferred route -- so that
+    callers can gate their scheduler / EMA update on it the way the reference's `continue` does (train_network.py:336-340)."""
     optimizer.zero_grad(set_to_none=True)
     if fused:
         from .fused import render_loss_fused
@@ -51,6 +54,8 @@ def train_step(model: torch.nn.Module, feats: torch.Tensor, batch: SyntheticBatc
         raw = model(feats)
         loss, _ = render_loss_forward(raw, batch, H, W, input_images, loss_kind, render_fn)
     loss.backward()
+    found_inf = False
+    deferred = False
     if clip_grad is not None:
         from .gradcheck import check_and_clip_deferred, check_and_clip_gradients
         params = [p for p in model.parameters() if p.grad is not None]
@@ -58,8 +63,16 @@ def train_step(model: torch.nn.Module, feats: torch.Tensor, batch: SyntheticBatc
             # fused optimizer on a HIP device: the NaN / Inf decision stays on the device (`found_inf` makes the optimizer skip the
             # step exactly when the reference's `if not valid: skip` would, train_network.py:336-340) -- no host read in the step
             check_and_clip_deferred(params, optimizer, clip_grad)
+            deferred = True
+            if return_found_inf:
+                found_inf = optimizer.found_inf.clone()         # (the state block is rewritten by the next step's stats pass)
         elif not check_and_clip_gradients(params, clip_grad):   # NaN/Inf: skip the step
             optimizer.zero_grad(set_to_none=True)
-            return loss.detach()
+            return (loss.detach(), True) if return_found_inf else loss.detach()
     optimizer.step()
-    return loss.detach()
+    if deferred:
+        # the decision belongs to THIS step only: a later step that does not go through check_and_clip_deferred (clip_grad=None,
+        # another code path) must not inherit a stale found_inf = 1 and silently skip every optimizer.step() after it
+        optimizer.found_inf = None
+        optimizer.grad_scale = None
+    return (loss.detach(), found_inf) if return_found_inf else loss.detach()
