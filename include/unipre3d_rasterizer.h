@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define U3D_ABI_VERSION 4
+#define U3D_ABI_VERSION 5
 
 /* flags (fields 11-13 of GaussianRasterizationSettings, gaussian_renderer/__init__.py:56-58) */
 #define U3D_FLAG_PREFILTERED 1   /* accepted, no effect: culled points are dropped either way */
@@ -229,6 +229,30 @@ int u3d_render_loss_step_backward(const u3d_raster_desc* desc, const u3d_head_de
                                   const float* center, const float* viewmatrix, const float* projmatrix, const float* campos,
                                   const int32_t* radii, const float* dloss, const void* geom, const void* binning, void* fused,
                                   void* backward_scratch, float* d_head_out, void* stream);
+
+/*
+ * The body of the reference's per-view wrapper as ONE launch sequence (ABI 5): replaces, inside `render_predicted`,
+ *   gaussian_renderer/__init__.py:78-79   shs = torch.cat([features_dc, features_rest], dim=1)   (a new (P, M, 3) tensor per view),
+ *   gaussian_renderer/__init__.py:89-97   the operator call, whose third output (inverse depth) the wrapper drops, and
+ *   gaussian_renderer/__init__.py:100-104 "visibility_filter": radii > 0.
+ * The SH coefficients are read through TWO pointers -- features_dc [n_items][P][1][3] (coefficient 0) and features_rest
+ * [n_items][P][M-1][3] (coefficients 1..M-1; NULL iff M == 1) with desc->sh_coeffs = M -- and their gradients are written through two
+ * pointers as well, so neither the concatenation nor its backward (two strided copies per view) exists.  No inverse-depth plane
+ * is written (the tile kernel's variant without it).  visibility [n_views][P] (uint8, may be NULL) = radii > 0, written by the
+ * projection kernel.  Everything else -- arguments, scratch, ownership, ragged batches, error codes -- as u3d_rasterize_forward /
+ * u3d_rasterize_backward (dL_dinvdepth is taken as zero: that output does not exist here).  The reference calls the wrapper once
+ * per object and view (train_network.py:418-446), where launches, not bytes, are the cost: 2 launches forward, 3 backward.
+ */
+int u3d_render_view_forward(const u3d_raster_desc* desc, const float* bg, const float* means3D, const float* features_dc,
+                            const float* features_rest, const float* opacities, const float* scales, const float* rotations,
+                            const float* viewmatrix, const float* projmatrix, const float* campos, float* out_color,
+                            int32_t* radii, uint8_t* visibility, void* geom, void* binning, void* image, void* stream);
+int u3d_render_view_backward(const u3d_raster_desc* desc, const float* bg, const float* means3D, const float* features_dc,
+                             const float* features_rest, const float* opacities, const float* scales, const float* rotations,
+                             const float* viewmatrix, const float* projmatrix, const float* campos, const int32_t* radii,
+                             const float* dL_dcolor, const void* geom, const void* binning, const void* image,
+                             void* backward_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dfeatures_dc,
+                             float* dL_dfeatures_rest, float* dL_dopacity, float* dL_dscales, float* dL_drotations, void* stream);
 
 /* Frustum test only: replaces `_C.mark_visible` (no caller in the reference tree). present[P] = z_view > 0.2 */
 int u3d_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert set(names) == set(_lib.EXPORTS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.u3d_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.u3d_abi_version() == _lib.ABI_VERSION == 5
     assert lib.u3d_error_string(0) == b"ok" and b"invalid" in lib.u3d_error_string(1)
 
 

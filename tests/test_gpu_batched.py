@@ -707,6 +707,56 @@ def test_train_step_does_not_leave_a_stale_found_inf_on_the_optimizer():
     assert any(not torch.equal(x, p.detach()) for x, p in zip(w0, model.parameters()))
 
 
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_render_predicted_one_call_body_equals_the_op_by_op_body(oracle_mod, deg):
+    """renderer.render_predicted on a HIP device is ONE binding call (u3d_render_view_*: split SH pointers, cached zero leaf as
+    `viewspace_points`, visibility from the projection kernel, no inverse-depth plane).  Against the op-by-op body that mirrors
+    gaussian_renderer/__init__.py line by line (pinned by G3), and against the oracle: image, radii, visibility, the gradient of
+    every Gaussian parameter and `viewspace_points.grad`."""
+    import types
+    from unipre3d_amd import renderer
+    from scenes import scene, to_numpy
+    dev = torch.device("cuda:0")
+    H, W, P = 64, 80, 150
+    sc = scene(P, H, W, seed=7 + deg, level="object", compact=False, deg=deg)
+    cfg = types.SimpleNamespace(data=types.SimpleNamespace(fov=2 * math.degrees(math.atan(sc["tanfovx"])), training_height=H, training_width=W),
+                                model=types.SimpleNamespace(max_sh_degree=deg))
+    dcol = torch.randn(3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = {}
+    for fast in (True, False):
+        renderer.FAST_PATH = fast
+        try:
+            pc = {"xyz": sc["means3D"], "opacity": sc["opacities"], "scaling": sc["scales"], "rotation": sc["rotations"],
+                  "features_dc": sc["shs"][:, :1].contiguous(), "features_rest": sc["shs"][:, 1:].contiguous()}
+            pc = {k: v.to(dev).requires_grad_(True) for k, v in pc.items()}
+            out = renderer.render_predicted(pc, sc["viewmatrix"].to(dev), sc["projmatrix"].to(dev), sc["campos"].to(dev), sc["bg"].to(dev), cfg)
+            (out["render"] * dcol).sum().backward()
+            torch.cuda.synchronize()
+            res[fast] = (out, pc)
+        finally:
+            renderer.FAST_PATH = True
+    (a, pa), (b, pb) = res[True], res[False]
+    assert a["viewspace_points"].is_leaf and a["viewspace_points"].requires_grad and not bool(a["viewspace_points"].any())
+    assert torch.equal(a["radii"], b["radii"]) and torch.equal(a["visibility_filter"], b["visibility_filter"])
+    assert a["visibility_filter"].dtype == torch.bool and torch.equal(a["visibility_filter"], a["radii"] > 0)
+    assert rel_l2(a["render"].detach().cpu().numpy(), b["render"].detach().cpu().numpy()) < 1e-6
+    for k in pa:
+        if pa[k].numel():
+            assert pa[k].grad.shape == pb[k].grad.shape
+            assert rel_l2(pa[k].grad.cpu().numpy(), pb[k].grad.cpu().numpy()) < 1e-5, k
+    assert rel_l2(a["viewspace_points"].grad.cpu().numpy(), b["viewspace_points"].grad.cpu().numpy()) < 1e-5
+    r = oracle_mod.forward(dtype=np.float32, **to_numpy(sc))
+    go = oracle_mod.backward(r, dcol.cpu().numpy())
+    assert np.array_equal(a["radii"].cpu().numpy(), r.radii) and rel_l2(a["render"].detach().cpu().numpy(), r.color) < TOL
+    g_rest = pa["features_rest"].grad if pa["features_rest"].numel() else torch.zeros_like(pa["features_rest"])
+    gshs = torch.cat([pa["features_dc"].grad, g_rest], dim=1).cpu().numpy()
+    assert rel_l2(gshs, go["shs"]) < TOL and rel_l2(pa["xyz"].grad.cpu().numpy(), go["means3D"]) < TOL
+    assert rel_l2(a["viewspace_points"].grad.cpu().numpy(), go["means2D"]) < TOL
+    # two views of the same Gaussians: the cached zero storage is shared, the leaves (and their .grad) are not
+    s1 = renderer.render_predicted(pa, sc["viewmatrix"].to(dev), sc["projmatrix"].to(dev), sc["campos"].to(dev), sc["bg"].to(dev), cfg)["viewspace_points"]
+    assert s1 is not a["viewspace_points"] and s1.grad is None and a["viewspace_points"].grad is not None
+
+
 class _DropGrad(torch.autograd.Function):
     """y = x; hands NO gradient back (None): the node upstream is then run with an undefined grad_output."""
 

@@ -17,13 +17,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libunipre3d_rasterizer.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 4   # include/unipre3d_rasterizer.h: U3D_ABI_VERSION
+ABI_VERSION = 5   # include/unipre3d_rasterizer.h: U3D_ABI_VERSION
 FLAG_PREFILTERED, FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_EXACT_AA_GRAD, FLAG_STATS, FLAG_ACC_CLEAN = 1, 2, 4, 8, 16, 32
 
 EXPORTS = ("u3d_abi_version", "u3d_error_string", "u3d_scratch_query", "u3d_rasterize_forward",
            "u3d_rasterize_backward", "u3d_mark_visible", "u3d_profile_begin", "u3d_profile_end",
            "u3d_render_loss_forward", "u3d_render_loss_backward", "u3d_render_loss_step",
-           "u3d_render_loss_step_forward", "u3d_render_loss_step_backward")
+           "u3d_render_loss_step_forward", "u3d_render_loss_step_backward", "u3d_render_view_forward", "u3d_render_view_backward")
 PROFILE_KINDS = ("preprocess_fwd", "depth_sort", "render_fwd", "render_bwd", "preprocess_bwd", "render_fb")
 
 
@@ -100,6 +100,10 @@ def load() -> ctypes.CDLL:
     lib.u3d_render_loss_step_forward.argtypes = [ctypes.POINTER(RasterDesc), ctypes.POINTER(HeadDesc), ctypes.POINTER(LossDesc)] + [vp] * 15
     lib.u3d_render_loss_step_backward.restype = ctypes.c_int
     lib.u3d_render_loss_step_backward.argtypes = [ctypes.POINTER(RasterDesc), ctypes.POINTER(HeadDesc)] + [vp] * 13
+    lib.u3d_render_view_forward.restype = ctypes.c_int
+    lib.u3d_render_view_forward.argtypes = [ctypes.POINTER(RasterDesc)] + [vp] * 17
+    lib.u3d_render_view_backward.restype = ctypes.c_int
+    lib.u3d_render_view_backward.argtypes = [ctypes.POINTER(RasterDesc)] + [vp] * 24
     lib.u3d_profile_begin.restype = ctypes.c_int
     lib.u3d_profile_begin.argtypes = [i32]
     lib.u3d_profile_end.restype = ctypes.c_int

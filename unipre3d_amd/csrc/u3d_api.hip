@@ -277,6 +277,87 @@ int u3d_rasterize_backward(const u3d_raster_desc* desc, const float* bg, const f
   return finish(desc, s);
 }
 
+// The per-view wrapper's body (header: u3d_render_view_*): split SH pointers, no inverse-depth plane, visibility from the projection.
+int u3d_render_view_forward(const u3d_raster_desc* desc, const float* bg, const float* means3D, const float* features_dc,
+                            const float* features_rest, const float* opacities, const float* scales, const float* rotations,
+                            const float* viewmatrix, const float* projmatrix, const float* campos, float* out_color,
+                            int32_t* radii, uint8_t* visibility, void* geom, void* binning, void* image, void* stream) {
+  int rc = check_desc(desc);
+  if (rc != U3D_OK) return rc;
+  const u3d_raster_desc& d = *desc;
+  const int NV = d.n_items * d.views_per_item;
+  if (NV == 0) return U3D_OK;
+  if (!bg || !viewmatrix || !projmatrix || !campos || !out_color || !geom || !binning || !image) return U3D_ERR_INVALID_ARGUMENT;
+  if (d.P > 0) {
+    if (!means3D || !opacities || !radii || !features_dc || !scales || !rotations) return U3D_ERR_INVALID_ARGUMENT;
+    if (d.sh_coeffs < (d.sh_degree + 1) * (d.sh_degree + 1) || (d.sh_coeffs > 1) != (features_rest != nullptr)) return U3D_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = validate_offsets(d, geom, s)) != U3D_OK) return rc;
+  U3DBuffers b{};
+  u3d_carve(d, geom, binning, image, &b);
+  if (d.flags & U3D_FLAG_STATS) (void)hipMemsetAsync(b.num_rendered, 0, sizeof(uint32_t) * NV, s);
+  if (d.P == 0) (void)hipMemsetAsync(b.n_vis, 0, sizeof(uint32_t) * NV, s);
+  if (d.P > 0) {
+    U3DSource src = plain_source(d, means3D, features_dc, nullptr, opacities, scales, rotations, nullptr);
+    src.s_shs = 3;
+    src.shs_rest = features_rest; src.s_shs_rest = (d.sh_coeffs - 1) * 3;
+    {
+      ProfScope ps(0, s);
+      u3d_launch_preprocess_fwd(d, b, src, viewmatrix, projmatrix, campos, radii, nullptr, s, visibility);
+    }
+    if (!u3d_preprocess_sorts(d)) {
+      ProfScope ps(1, s);
+      u3d_launch_depth_sort(d, b, radii, s);
+    }
+  }
+  {
+    ProfScope ps(2, s);
+    u3d_launch_render_fwd(d, b, bg, out_color, nullptr, U3DLoss{}, s);
+  }
+  return finish(desc, s);
+}
+
+int u3d_render_view_backward(const u3d_raster_desc* desc, const float* bg, const float* means3D, const float* features_dc,
+                             const float* features_rest, const float* opacities, const float* scales, const float* rotations,
+                             const float* viewmatrix, const float* projmatrix, const float* campos, const int32_t* radii,
+                             const float* dL_dcolor, const void* geom, const void* binning, const void* image,
+                             void* backward_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dfeatures_dc,
+                             float* dL_dfeatures_rest, float* dL_dopacity, float* dL_dscales, float* dL_drotations, void* stream) {
+  int rc = check_desc(desc);
+  if (rc != U3D_OK) return rc;
+  const u3d_raster_desc& d = *desc;
+  const int NV = d.n_items * d.views_per_item;
+  if (NV == 0 || d.P == 0) return U3D_OK;
+  if (!bg || !means3D || !features_dc || !opacities || !scales || !rotations || !viewmatrix || !projmatrix || !campos || !radii ||
+      !dL_dcolor || !geom || !binning || !image || !backward_scratch || !dL_dmeans3D || !dL_dopacity || !dL_dfeatures_dc ||
+      !dL_dscales || !dL_drotations)
+    return U3D_ERR_INVALID_ARGUMENT;
+  if ((d.sh_coeffs > 1) != (features_rest != nullptr) || (features_rest != nullptr) != (dL_dfeatures_rest != nullptr))
+    return U3D_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  U3DBuffers b{};
+  const U3DLayout L = u3d_carve(d, (void*)geom, (void*)binning, (void*)image, &b);
+  double* acc = (double*)backward_scratch;
+  float* part = (float*)((char*)backward_scratch + L.acc_bytes);
+  if (!(d.flags & U3D_FLAG_ACC_CLEAN)) (void)hipMemsetAsync(acc, 0, L.acc_bytes, s);
+  {
+    ProfScope ps(3, s);
+    u3d_launch_render_bwd(d, b, bg, dL_dcolor, nullptr, nullptr, U3DLoss{}, acc, part, s);
+  }
+  {
+    ProfScope ps(4, s);
+    U3DSource src = plain_source(d, means3D, features_dc, nullptr, opacities, scales, rotations, nullptr);
+    src.s_shs = 3;
+    src.shs_rest = features_rest; src.s_shs_rest = (d.sh_coeffs - 1) * 3;
+    U3DGradSink sink{};
+    sink.means = dL_dmeans3D; sink.shs = dL_dfeatures_dc; sink.shs_rest = dL_dfeatures_rest; sink.opac = dL_dopacity;
+    sink.scales = dL_dscales; sink.rots = dL_drotations; sink.means2D = dL_dmeans2D;
+    u3d_launch_preprocess_bwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, sink, s, acc);
+  }
+  return finish(desc, s);
+}
+
 int u3d_render_loss_forward(const u3d_raster_desc* desc, const u3d_head_desc* head, const u3d_loss_desc* loss,
                             const float* bg, const float* head_out, const float* center, const float* viewmatrix,
                             const float* projmatrix, const float* campos, const float* gt, float* out_color,

@@ -106,6 +106,9 @@ __device__ __forceinline__ void u3d_view_span(const U3DSpan& s, int view, int& P
 struct U3DSource {
   const float* means;   int s_means;    // element stride between consecutive Gaussians
   const float* shs;     int s_shs;
+  // split SH (u3d_render_view_*): `shs` holds coefficient 0 only (features_dc [P][1][3], stride 3) and coefficients 1.. come from
+  // `shs_rest` (features_rest [P][M-1][3], stride 3 (M-1)) -- what gaussian_renderer/__init__.py:79 concatenates per view; null otherwise
+  const float* shs_rest; int s_shs_rest;
   const float* colors;  // [P][3] precomputed colours or null
   const float* opac;    int s_opac;
   const float* scales;  int s_scales;
@@ -125,6 +128,7 @@ struct U3DSource {
 // Where per-Gaussian gradients go (same strides as the source; act != 0 chains through the activations).
 struct U3DGradSink {
   float* means; float* shs; float* colors; float* opac; float* scales; float* rots; float* cov;
+  float* shs_rest;      // split SH: gradient of coefficients 1.. (same layout as U3DSource::shs_rest), else null
   float* means2D;       // [NV][P][3] or null
   float* qdot;          // [B][4] sum_i raw_rot[i][c] * g[i][c]  (act == 1; finished by u3d_quat_fixup)
 };
@@ -231,7 +235,8 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
 
 // launchers (one per translation unit)
 void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
-                               const float* projmatrix, const float* campos, int32_t* radii, double* acc_zero, hipStream_t s);
+                               const float* projmatrix, const float* campos, int32_t* radii, double* acc_zero, hipStream_t s,
+                               uint8_t* visible = nullptr);   // visible[pair] = radius > 0 (`visibility_filter`, gaussian_renderer/__init__.py:103)
 // (preprocess_bwd triages by b.touched_words when d.P > U3D_LDS_SORT_MAX; the reduction kernels set the bits in that case)
 static inline bool u3d_uses_touched_words(const u3d_raster_desc& d) { return d.P > U3D_LDS_SORT_MAX; }
 // large-P sort: the tile kernels read a sorted entry's rectangle through sorted_id (b.rect) instead of a sorted copy (b.sorted_rect)

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     float4* __restrict__ rgbd, uint2* __restrict__ rect, uint32_t* __restrict__ clamped,
     uint32_t* __restrict__ num_rendered, double* __restrict__ acc_zero, size_t NG, uint32_t* __restrict__ sorted_id,
     uint2* __restrict__ sorted_rect, uint32_t* __restrict__ n_vis, uint32_t* __restrict__ msd_total, int msd_bins,
-    uint32_t* __restrict__ touched_words) {
+    uint32_t* __restrict__ touched_words, uint8_t* __restrict__ visible) {
   // (msd_total != null: P > 4096; the depth sort that follows partitions by depth bucket with one global atomic per (workgroup,
   // bucket) on these per-view totals -- the first workgroup of every (set, view slice) clears them here instead of a memset node)
   if (msd_total && blockIdx.x == 0) {
@@ -212,8 +212,14 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     }
     if (!src.colors) {
       const float* sh = lsrc.shs + li * (size_t)lsrc.s_shs;
+      if (lsrc.shs_rest) {   // split SH: coefficient 0 from features_dc, the rest from features_rest
+        const float* shr = lsrc.shs_rest + li * (size_t)lsrc.s_shs_rest;
 #pragma unroll
-      for (int k = 0; k < K * 3; ++k) shc[k] = sh[k];
+        for (int k = 0; k < K * 3; ++k) shc[k] = k < 3 ? sh[k] : shr[k - 3];
+      } else {
+#pragma unroll
+        for (int k = 0; k < K * 3; ++k) shc[k] = sh[k];
+      }
     }
   }
   for (int vk = v0; vk < v1; ++vk) {
@@ -282,6 +288,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
       }
     }
     radii[g] = radius;
+    if (visible) visible[g] = radius > 0 ? 1 : 0;
     depth[g] = radius > 0 ? zv : 0.f;
     xy[g] = pix;
     conic_op[g] = co;
@@ -406,7 +413,13 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
       }
       if (sink.shs) {
         float* o = sink.shs + gi * (size_t)src.s_shs;
-        for (int k = 0; k < M * 3; ++k) o[k] = 0.f;
+        if (sink.shs_rest) {
+          float* orr = sink.shs_rest + gi * (size_t)src.s_shs_rest;
+          o[0] = o[1] = o[2] = 0.f;
+          for (int k = 3; k < M * 3; ++k) orr[k - 3] = 0.f;
+        } else {
+          for (int k = 0; k < M * 3; ++k) o[k] = 0.f;
+        }
       }
       if (sink.scales) {
 #pragma unroll
@@ -550,7 +563,8 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
       dmean[k] += (cam.Pm[k * 4] * m_w - cam.Pm[k * 4 + 3] * mul1) * a[0] + (cam.Pm[k * 4 + 1] * m_w - cam.Pm[k * 4 + 3] * mul2) * a[1];
     dcol[0] += a[6]; dcol[1] += a[7]; dcol[2] += a[8];
     if (shs) {
-      const float* sh = shs + gi * (size_t)src.s_shs;
+      // (coefficients 1.. : `sh` itself, or -- split SH -- features_rest re-based so that sh[3 + ...] addresses it)
+      const float* sh = src.shs_rest ? src.shs_rest + gi * (size_t)src.s_shs_rest - 3 : shs + gi * (size_t)src.s_shs;
       const float dorig[3] = {p[0] - cam.pos[0], p[1] - cam.pos[1], p[2] - cam.pos[2]};
       const float sum2 = dorig[0] * dorig[0] + dorig[1] * dorig[1] + dorig[2] * dorig[2];
       const float inv = 1.f / sqrtf(sum2);
@@ -682,9 +696,16 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     }
     if (sink.shs) {
       float* o = sink.shs + gi * (size_t)src.s_shs;
+      if (sink.shs_rest) {
+        float* orr = sink.shs_rest + gi * (size_t)src.s_shs_rest;
 #pragma unroll
-      for (int k = 0; k < K * 3; ++k) o[k] = dsh[k];
-      for (int k = K * 3; k < M * 3; ++k) o[k] = 0.f;
+        for (int k = 0; k < K * 3; ++k) { if (k < 3) o[k] = dsh[k]; else orr[k - 3] = dsh[k]; }
+        for (int k = K * 3; k < M * 3; ++k) orr[k - 3] = 0.f;
+      } else {
+#pragma unroll
+        for (int k = 0; k < K * 3; ++k) o[k] = dsh[k];
+        for (int k = K * 3; k < M * 3; ++k) o[k] = 0.f;
+      }
     }
     if (sink.scales) {
 #pragma unroll
@@ -772,7 +793,8 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 bool u3d_preprocess_sorts(const u3d_raster_desc& d) { return d.P <= U3D_BLOCK; }
 
 void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
-                               const float* projmatrix, const float* campos, int32_t* radii, double* acc_zero, hipStream_t s) {
+                               const float* projmatrix, const float* campos, int32_t* radii, double* acc_zero, hipStream_t s,
+                               uint8_t* visible) {
   const bool fuse_sort = u3d_preprocess_sorts(d);
   const size_t NG = (size_t)d.views_per_item * u3d_total_P(d);
   // enough Gaussians to fill the chip by themselves -> one thread walks several views of its set (the view-independent work --
@@ -789,7 +811,7 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
                      d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, src, viewmatrix, projmatrix, campos, \
                      radii, b.depth, b.xy, b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered, acc_zero, NG,               \
                      fuse_sort ? b.sorted_id : nullptr, b.sorted_rect, b.n_vis, d.P > U3D_LDS_SORT_MAX ? b.sort_hist : nullptr, u3d_msd_bins(d.P), \
-                     u3d_uses_touched_words(d) ? b.touched_words : nullptr)
+                     u3d_uses_touched_words(d) ? b.touched_words : nullptr, visible)
   switch (D) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;

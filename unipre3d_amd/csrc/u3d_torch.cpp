@@ -261,6 +261,122 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
   }
 };
 
+// ---- the per-view wrapper's body as one call (u3d_render_view_*): `render_predicted` of gaussian_renderer/__init__.py:13-104 ------
+// The reference calls the wrapper once per object and view; each PyTorch-level op it contains costs the host ~8-10 us and the GPU a
+// dispatch slot, which -- not bytes -- is what that route is bound by (profiles/r04: 8 % GPU busy).  This function is the whole body:
+//   * `screenspace_points = zeros_like(xyz, requires_grad=True) + 0` (a fill, an add and an AddBackward node per view): a fresh LEAF
+//     that shares one cached all-zero storage per (device, P) -- same value, same role (its .grad receives dL/dmean2D), no launch;
+//     the zeros are shared, so they must not be modified in place (the reference never does);
+//   * `torch.cat([features_dc, features_rest], dim=1)` and its backward: the kernels read / write SH through two pointers;
+//   * `radii > 0`: written by the projection kernel;
+//   * the inverse-depth plane the wrapper drops is not produced.
+std::mutex g_sink_mu;
+auto* g_sink = new std::map<std::pair<int, int64_t>, Tensor>();   // (heap, never destroyed)
+Tensor viewspace_sink(const Tensor& xyz) {
+  Tensor z;
+  {
+    std::lock_guard<std::mutex> lock(g_sink_mu);
+    const std::pair<int, int64_t> key{(int)xyz.device().index(), xyz.numel()};
+    auto it = g_sink->find(key);
+    if (it == g_sink->end()) {
+      if (g_sink->size() >= 64) g_sink->clear();
+      it = g_sink->emplace(key, at::zeros({xyz.numel()}, xyz.options().dtype(at::kFloat))).first;
+    }
+    z = it->second;
+  }
+  Tensor leaf = z.view(xyz.sizes()).detach();
+  leaf.set_requires_grad(true);
+  return leaf;
+}
+
+struct RenderViewFn : public torch::autograd::Function<RenderViewFn> {
+  using OptTensor = c10::optional<Tensor>;
+  static variable_list forward(AutogradContext* ctx, Tensor xyz, Tensor sink, Tensor dc, OptTensor rest_, Tensor opac, Tensor scales,
+                               Tensor rots, Tensor view, Tensor proj, Tensor campos, Tensor bg, int64_t H, int64_t W, double tanfovx,
+                               double tanfovy, double scale_modifier, int64_t sh_degree, int64_t flags) {
+    const c10::Device dev = xyz.device();
+    TORCH_CHECK(dev.is_cuda(), "the MI355X rasterizer needs tensors on a HIP device; there is no CPU fallback");
+    const Tensor rest = rest_.has_value() ? *rest_ : Tensor();
+    const int64_t P = xyz.numel() / 3;
+    const int64_t M = 1 + (rest.defined() && P > 0 ? rest.numel() / (3 * P) : 0);
+    TORCH_CHECK(xyz.dim() == 2 && xyz.size(1) == 3, "xyz must be (P, 3)");
+    TORCH_CHECK(dc.numel() == P * 3 && opac.numel() == P && scales.numel() == P * 3 && rots.numel() == P * 4 && sink.numel() == P * 3 &&
+                    (!rest.defined() || rest.numel() == P * (M - 1) * 3),
+                "features_dc (P,1,3), features_rest (P,M-1,3), opacity (P,1), scaling (P,3), rotation (P,4) must match xyz (P,3)");
+    TORCH_CHECK(view.numel() == 16 && proj.numel() == 16 && campos.numel() == 3 && bg.numel() == 3, "cameras must be (4,4), (4,4), (3,) and bg (3,)");
+    u3d_raster_desc d{};
+    d.n_items = 1; d.views_per_item = 1; d.P = (int32_t)P; d.image_height = (int32_t)H; d.image_width = (int32_t)W;
+    d.tanfovx = (float)tanfovx; d.tanfovy = (float)tanfovy; d.scale_modifier = (float)scale_modifier;
+    d.sh_degree = (int32_t)sh_degree; d.sh_coeffs = (int32_t)M; d.flags = (int32_t)flags;
+    const Plan plan = plan_for(d);
+    const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+    Tensor color = at::empty({3, H, W}, fopt);
+    Tensor radii = at::empty({P}, fopt.dtype(at::kInt));
+    Tensor visible = at::empty({P}, fopt.dtype(at::kBool));
+    Tensor arena = at::empty({(int64_t)plan.fwd_scratch}, fopt.dtype(at::kByte));
+    char* base = (char*)arena.data_ptr();
+    u3d_raster_desc dd = d;
+    const int rc = u3d_render_view_forward(&dd, fptr(bg), fptr(xyz), fptr(dc), M > 1 ? fptr(rest) : nullptr, fptr(opac), fptr(scales), fptr(rots),
+                                           fptr(view), fptr(proj), fptr(campos), color.data_ptr<float>(), P > 0 ? radii.data_ptr<int32_t>() : nullptr,
+                                           P > 0 ? (uint8_t*)visible.data_ptr() : nullptr, base, base + plan.o_binning, base + plan.o_image,
+                                           current_stream(dev));
+    TORCH_CHECK(rc == U3D_OK, "u3d_render_view_forward failed: ", u3d_error_string(rc), " (code ", rc, ")");
+    ctx->saved_data["plan"] = plan_save(plan);
+    ctx->save_for_backward({xyz, dc, rest, opac, scales, rots, view, proj, campos, bg, radii, arena});
+    ctx->mark_non_differentiable({radii, visible});
+    ctx->set_materialize_grads(false);
+    return {color, radii, visible};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const Plan plan = plan_load(ctx->saved_data["plan"].toStringRef());
+    auto sv = ctx->get_saved_variables();
+    const Tensor &xyz = sv[0], &dc = sv[1], &rest = sv[2], &opac = sv[3], &scales = sv[4], &rots = sv[5], &view = sv[6], &proj = sv[7],
+                 &campos = sv[8], &bg = sv[9], &radii = sv[10], &arena = sv[11];
+    const u3d_raster_desc& d = plan.d;
+    const c10::Device dev = xyz.device();
+    const int64_t P = d.P, M = d.sh_coeffs;
+    const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+    variable_list out(18);
+    if (!grads[0].defined() || P == 0) return out;      // the image was not used downstream: no gradient flows
+    const Tensor gcol = f32c(grads[0], dev);
+    Tensor g_xyz = at::empty({P, 3}, fopt), g_sink = at::empty({P, 3}, fopt), g_dc = at::empty({P, 1, 3}, fopt);
+    Tensor g_rest = M > 1 ? at::empty({P, M - 1, 3}, fopt) : Tensor();
+    Tensor g_op = at::empty({P, 1}, fopt), g_scales = at::empty({P, 3}, fopt), g_rots = at::empty({P, 4}, fopt);
+    void* stream = current_stream(dev);
+    const WsKey key{(int)dev.index(), stream};
+    const std::string shape_key = desc_key(plan.d);
+    const Lease lease = workspace_acquire(key, plan, shape_key, fopt.dtype(at::kByte));
+    u3d_raster_desc dd = plan.d;
+    if (lease.clean) dd.flags |= U3D_FLAG_ACC_CLEAN;
+    const char* base = (const char*)arena.data_ptr();
+    const int rc = u3d_render_view_backward(&dd, fptr(bg), fptr(xyz), fptr(dc), M > 1 ? fptr(rest) : nullptr, fptr(opac), fptr(scales), fptr(rots),
+                                            fptr(view), fptr(proj), fptr(campos), radii.data_ptr<int32_t>(), fptr(gcol), base,
+                                            base + plan.o_binning, base + plan.o_image, lease.buf.data_ptr(), fptr_mut(g_xyz), fptr_mut(g_sink),
+                                            fptr_mut(g_dc), M > 1 ? fptr_mut(g_rest) : nullptr, fptr_mut(g_op), fptr_mut(g_scales),
+                                            fptr_mut(g_rots), stream);
+    workspace_release(key, lease.ticket, shape_key, rc == U3D_OK);
+    TORCH_CHECK(rc == U3D_OK, "u3d_render_view_backward failed: ", u3d_error_string(rc), " (code ", rc, ")");
+    out[0] = g_xyz; out[1] = g_sink; out[2] = g_dc; out[3] = g_rest; out[4] = g_op.view(opac.sizes()); out[5] = g_scales; out[6] = g_rots;
+    return out;
+  }
+};
+
+// (color (3,H,W), viewspace_points (P,3) leaf, radii (P,) int32, visibility_filter (P,) bool)
+std::tuple<Tensor, Tensor, Tensor, Tensor> render_view(const Tensor& xyz, const Tensor& opacity, const Tensor& scaling, const Tensor& rotation,
+                                                       const Tensor& features_dc, const c10::optional<Tensor>& features_rest, const Tensor& view,
+                                                       const Tensor& proj, const Tensor& campos, const Tensor& bg, int64_t H, int64_t W,
+                                                       double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree, int64_t flags) {
+  const c10::Device dev = xyz.device();
+  const Tensor x = f32c(xyz, dev);
+  Tensor sink = viewspace_sink(x);
+  c10::optional<Tensor> rest;
+  if (features_rest.has_value() && features_rest->defined() && features_rest->numel() > 0) rest = f32c(*features_rest, dev);
+  auto r = RenderViewFn::apply(x, sink, f32c(features_dc, dev), rest, f32c(opacity, dev), f32c(scaling, dev), f32c(rotation, dev), f32c(view, dev),
+                               f32c(proj, dev), f32c(campos, dev), f32c(bg, dev), H, W, tanfovx, tanfovy, scale_modifier, sh_degree, flags);
+  return {r[0], sink, r[1], r[2]};
+}
+
 // ---- fused render-loss training step (u3d_render_loss_step): activations + render + loss + backward in one launch sequence ------
 // One call per training step, but its host cost is exposed whenever a step's kernels are short (C1, C3: 7 launches in ~0.1 ms).
 std::mutex g_unit_mu;
@@ -483,6 +599,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("rotations"), py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("campos"), py::arg("bg"),
         py::arg("n_items"), py::arg("views_per_item"), py::arg("H"), py::arg("W"), py::arg("tanfovx"), py::arg("tanfovy"),
         py::arg("scale_modifier"), py::arg("sh_degree"), py::arg("flags"), py::arg("item_offsets") = py::none(), py::arg("max_P") = 0);
+  m.def("render_view", &render_view,
+        "the reference wrapper's body for one view (u3d_render_view_*): image, viewspace_points leaf, radii, visibility_filter");
+  m.def("viewspace_sink", &viewspace_sink, "a fresh zero-valued leaf (requires_grad) shaped like xyz, sharing one cached zero storage");
   m.def("render_loss_step", &render_loss_step,
         "fused training step (u3d_render_loss_step): loss, [images], radii; autograd's backward returns the stored d loss / d head_out");
   m.def("unit_tensor", &unit_tensor, "the cached dL/dloss = 1 tensor of a device (fused.backward_unit)");
