@@ -362,7 +362,7 @@ def gradclip_region(net, nparam, reps=20):
     return res
 
 
-def per_view_region(batch, B, P, V, H, W, loss_kind, steps=5):
+def per_view_region(batch, B, P, V, H, W, loss_kind, steps=9):
     """The reference's UNCHANGED call pattern through the drop-in module: head activations in torch, then one
     `render_predicted` -> `GaussianRasterizer` call per object and view (train_network.py:418-446 ->
     gaussian_renderer/__init__.py:13-104), torch.stack, torch loss, loss.backward(): B*V operator forwards and B*V operator
@@ -391,21 +391,26 @@ def per_view_region(batch, B, P, V, H, W, loss_kind, steps=5):
         return loss.detach()
 
     def run(n):
+        """n steps, each fenced by a synchronise (the route is host-bound: a step's kernels finish with its issue); returns
+        (total seconds, host issue seconds, last loss, sorted per-step milliseconds)."""
         for _ in range(2):
             step_fn()
         torch.cuda.synchronize()
         host[0] = 0.0
-        t0 = time.perf_counter()
+        per = []
         for _ in range(n):
+            t0 = time.perf_counter()
             l = step_fn()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0, host[0], l
+            torch.cuda.synchronize()
+            per.append(1e3 * (time.perf_counter() - t0))
+        return 1e-3 * sum(per), host[0], l, sorted(per)
 
-    el, host_el, l = run(steps)
-    out = {"ms_per_step": 1e3 * el / steps, "value": B * V * steps / el, "unit": "views/s", "host_issue_ms_per_step": 1e3 * host_el / steps,
+    el, host_el, l, per = run(steps)
+    out = {"ms_per_step": 1e3 * el / steps, "ms_per_step_median": per[len(per) // 2], "ms_per_step_min": per[0], "steps": steps,
+           "value": B * V * steps / el, "unit": "views/s", "host_issue_ms_per_step": 1e3 * host_el / steps,
            "operator_calls_per_step": 2 * B * V, "us_per_forward_backward_pair": 1e6 * el / steps / (B * V), "final_loss": float(l),
-           "what": "reference call pattern unchanged: render_predicted per object and view through the drop-in "
-                   "diff_gaussian_rasterization module (C++ autograd binding over the C-ABI), torch.stack, torch loss, loss.backward()"}
+           "what": "reference call pattern unchanged: render_predicted per object and view (renderer.render_predicted: ONE binding call per "
+                   "view, u3d_render_view_forward/_backward over the C-ABI), torch.stack, torch loss, loss.backward(); every step fenced by a synchronise"}
     # the control: the SAME loop with a NO-OP operator (same inputs / outputs / autograd node, allocations only, no kernel), i.e. what
     # the wrapper around the operator costs by itself (slicing, zeros_like, SH concat, radii > 0, torch.stack, loss, autograd through
     # all of them); the operator's share of the route is the difference
@@ -424,11 +429,19 @@ def per_view_region(batch, B, P, V, H, W, loss_kind, steps=5):
 
     prev = _rz.set_operator_override(lambda *tensors: _NullOp.apply(*tensors) + (None,))
     try:
-        el0, host0, _ = run(steps)
+        el0, host0, _, per0 = run(steps)
     finally:
         _rz.set_operator_override(prev)
-    out.update({"noop_operator_ms": 1e3 * el0 / steps, "noop_operator_host_issue_ms": 1e3 * host0 / steps,
-                "operator_share_ms": 1e3 * (el - el0) / steps,
+    # round 3's op-by-op wrapper body (zeros_like + 0, torch.cat, nn.Module per call, radii > 0 around the per-view operator)
+    from unipre3d_amd import renderer as _rd
+    _rd.FAST_PATH = False
+    try:
+        el3, _, _, per3 = run(steps)
+    finally:
+        _rd.FAST_PATH = True
+    out.update({"noop_operator_ms": 1e3 * el0 / steps, "noop_operator_ms_median": per0[len(per0) // 2], "noop_operator_host_issue_ms": 1e3 * host0 / steps,
+                "operator_share_ms": 1e3 * (el - el0) / steps, "operator_share_ms_median": per[len(per) // 2] - per0[len(per0) // 2],
+                "op_by_op_wrapper_body_ms": 1e3 * el3 / steps, "op_by_op_wrapper_body_ms_median": per3[len(per3) // 2],
                 "noop_what": "the same loop with the operator replaced by an autograd node that only allocates its outputs and gradients: "
                              "the wrapper's own launches; operator_share_ms = ms_per_step - noop_operator_ms"})
     return out

@@ -54,6 +54,13 @@ extern "C" {
                                     Gaussian) pair: most of the step's projection-kernel traffic at scene level, one launch per call of
                                     the per-view operator route */
 
+#define U3D_FLAG_SPARSE_BWD 64   /* u3d_render_loss_step_forward / _backward (scene-level head, P > 4096 only; ignored otherwise): the
+                                    caller hands the forward half the gradient buffer `d_head_out` it will pass to the backward half.
+                                    The forward half zero-fills it (extra workgroups of the gradient reduction, off the critical path)
+                                    and records which Gaussians received a gradient; the backward half then runs the chain rule over
+                                    those few thousand instead of visiting every one of the scene's 10^5 Gaussians.  Set the flag in
+                                    BOTH halves' descriptors or in neither */
+
 #define U3D_OK 0
 #define U3D_ERR_INVALID_ARGUMENT 1
 #define U3D_ERR_UNSUPPORTED 2
@@ -224,7 +231,8 @@ int u3d_render_loss_step_forward(const u3d_raster_desc* desc, const u3d_head_des
                                  const float* bg, const float* head_out, const float* center, const float* viewmatrix,
                                  const float* projmatrix, const float* campos, const float* gt, float* out_color,
                                  int32_t* radii, float* loss_out, void* geom, void* binning, void* fused,
-                                 void* backward_scratch, void* stream);
+                                 void* backward_scratch, float* d_head_out /* U3D_FLAG_SPARSE_BWD: required; else may be NULL */,
+                                 void* stream);
 int u3d_render_loss_step_backward(const u3d_raster_desc* desc, const u3d_head_desc* head, const float* head_out,
                                   const float* center, const float* viewmatrix, const float* projmatrix, const float* campos,
                                   const int32_t* radii, const float* dloss, const void* geom, const void* binning, void* fused,
@@ -241,7 +249,8 @@ int u3d_render_loss_step_backward(const u3d_raster_desc* desc, const u3d_head_de
  * is written (the tile kernel's variant without it).  visibility [n_views][P] (uint8, may be NULL) = radii > 0, written by the
  * projection kernel.  Everything else -- arguments, scratch, ownership, ragged batches, error codes -- as u3d_rasterize_forward /
  * u3d_rasterize_backward (dL_dinvdepth is taken as zero: that output does not exist here).  The reference calls the wrapper once
- * per object and view (train_network.py:418-446), where launches, not bytes, are the cost: 2 launches forward, 3 backward.
+ * per object and view (train_network.py:418-446), where launches, not bytes, are the cost: 2 launches forward, 3 backward
+ * (the same fixed-order gradient reduction as the operator: run-to-run bit-identical).
  */
 int u3d_render_view_forward(const u3d_raster_desc* desc, const float* bg, const float* means3D, const float* features_dc,
                             const float* features_rest, const float* opacities, const float* scales, const float* rotations,

@@ -8,10 +8,16 @@ Two levels, both in fp32 (the restatement at the kernels' own precision) and fp6
     chained through the reference's activations (unipre3d_amd/head.py, pinned by golden G2) in the same dtype and the
     render loss of utils/loss_utils.py (pinned by G4), with the oracle as the differentiable renderer.
 
-Parity bar (`assert_parity`): <= 1e-4 relative L2 of the fp64 arbiter (north_star), or -- for ill-conditioned draws, where
-fp32 arithmetic itself cannot do better -- <= k x the fp32 restatement's own measured distance from the fp64 arbiter, and never
-more than GAP_CEIL x the tolerance in absolute terms.  The measured distances are returned so that tests can print / bound
-them; cases that pass only through the gap branch are collected in `GAP_PASSES` (printed by the tests that use -s).
+Parity bar -- ONE rule for every comparison that brings both restatements (`assert_parity`; tests/test_gpu_parity.py's old
+`near()` is gone).  With e64 / e32 = relative L2 distance of the HIP result from the fp64 arbiter / the fp32 restatement and
+gap = the fp32 restatement's own distance from the fp64 arbiter:
+    pass  <=>  e64 <= tol                                            (north_star: 1e-4 of the arbiter)
+           or  e64 <= k * gap  and  (e32 <= tol  or  e64 <= GAP_CEIL * tol)
+i.e. where fp32 arithmetic itself cannot resolve the quantity to 1e-4 (ill-conditioned draws; a pixel on the other side of a
+discrete threshold), the result may sit as far from the arbiter as k x the fp32 restatement does -- provided it either agrees with
+that restatement to the tolerance (the reference operator IS fp32: this is north_star's own criterion) or stays under an
+absolute cap.  Every pass through the second line is collected in `GAP_PASSES` and listed at the end of the pytest session
+(tests/conftest.py), so a regression that starts leaning on it shows in the GPUTEST tail.
 """
 from __future__ import annotations
 
@@ -33,9 +39,13 @@ def parity_errors(x, o32, o64):
     return rel_l2(x, o64), rel_l2(x, o32), rel_l2(o32, o64)
 
 
+def _rule(e64, e32, gap, tol, k):
+    return e64 <= tol or (e64 <= k * gap and (e32 <= tol or e64 <= GAP_CEIL * tol))
+
+
 def parity_ok(x, o32, o64, tol=TOL, k=GAP_K):
     e64, e32, gap = parity_errors(x, o32, o64)
-    return e64 <= tol or e64 <= min(k * gap, GAP_CEIL * tol)
+    return _rule(e64, e32, gap, tol, k)
 
 
 def assert_parity(x, o32, o64, what="", tol=TOL, k=GAP_K):
@@ -45,10 +55,11 @@ def assert_parity(x, o32, o64, what="", tol=TOL, k=GAP_K):
         assert not np.any(x), f"{what}: oracle is all-zero, HIP is not"
         return 0.0, 0.0, 0.0
     e64, e32, gap = parity_errors(x.reshape(o64.shape), o32, o64)
-    assert e64 <= tol or e64 <= min(k * gap, GAP_CEIL * tol), \
-        f"{what}: |hip-f64| {e64:.2e}, |hip-f32| {e32:.2e}, fp32 restatement's own gap |f32-f64| {gap:.2e} (bar {tol:.0e} or {k:g} x gap, capped at {GAP_CEIL * tol:.0e})"
+    assert _rule(e64, e32, gap, tol, k), \
+        (f"{what}: |hip-f64| {e64:.2e}, |hip-f32| {e32:.2e}, fp32 restatement's own gap |f32-f64| {gap:.2e} (bar {tol:.0e}, or {k:g} x gap "
+         f"with |hip-f32| <= {tol:.0e} or under the cap {GAP_CEIL * tol:.0e})")
     if e64 > tol:
-        GAP_PASSES.append((what, e64, gap))
+        GAP_PASSES.append((what + (" [= fp32 restatement]" if e32 <= tol else " [capped gap]"), e64, gap))
     return e64, e32, gap
 
 

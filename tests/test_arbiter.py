@@ -59,3 +59,24 @@ def test_g10_chain_known_answers_pin_the_arbiter(golden, oracle_mod, level, kind
         assert abs(l - float(g["loss"])) <= (1e-12 if dt == np.float64 else 1e-6) * max(1.0, abs(float(g["loss"]))) or abs(l - float(g["loss"])) < 1e-7, (l, float(g["loss"]))
         assert e < tol, (dt, e)
         print("g10 chain", level, dt.__name__, f"{e:.1e}")
+
+
+def test_the_one_parity_rule():
+    """tests/arbiter.py::assert_parity on synthetic vectors: 1e-4 of the arbiter passes; beyond it only under k x the fp32
+    restatement's own gap AND (agreement with that restatement to 1e-4, or the absolute cap); the second line is logged."""
+    import arbiter
+    o64 = np.ones(1000)
+    mk = lambda e: o64 * (1.0 + e)              # a vector at relative distance e from the arbiter
+    n0 = len(arbiter.GAP_PASSES)
+    arbiter.assert_parity(mk(5e-5), mk(2e-5), o64, "within tol")
+    assert len(arbiter.GAP_PASSES) == n0
+    arbiter.assert_parity(mk(3.6e-3), mk(3.6e-3 + 1e-6), o64, "equals the fp32 restatement, far from fp64")      # uncapped: e32 <= tol
+    arbiter.assert_parity(mk(5e-4), mk(3e-4), o64, "capped gap")                                                  # e32 = 2e-4 > tol, under the cap
+    assert len(arbiter.GAP_PASSES) == n0 + 2 and "[= fp32 restatement]" in arbiter.GAP_PASSES[n0][0] and "[capped gap]" in arbiter.GAP_PASSES[n0 + 1][0]
+    del arbiter.GAP_PASSES[n0:]
+    for x, o32 in ((mk(3e-3), mk(2e-3)),        # beyond the cap and not equal to the fp32 restatement
+                   (mk(5e-4), mk(2e-4)),        # farther from the arbiter than 2 x the restatement's own gap
+                   (mk(2e-4), mk(1e-6))):       # the restatement resolves the quantity: no allowance
+        with pytest.raises(AssertionError):
+            arbiter.assert_parity(x, o32, o64, "must fail")
+    assert len(arbiter.GAP_PASSES) == n0

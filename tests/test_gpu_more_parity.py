@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from arbiter import assert_parity, assert_radii
+from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -126,3 +127,127 @@ def test_batched_precomputed_colours_and_covariances_vs_oracle(oracle_mod, ragge
         g32, g64 = oracle_mod.backward(r32, dcol[i].numpy()), oracle_mod.backward(r64, dcol[i].numpy().astype(np.float64))
         for k, ok in (("means3D", "means3D"), ("opacities", "opacities"), ("cov", "cov3D_precomp"), ("colors", "colors_precomp")):
             assert_parity(leaf[i][k].grad.cpu().numpy(), g32[ok], g64[ok], f"d{ok} set {i}")
+
+
+def _step_via_cabi(bd, H, W, level, flags, prefill):
+    """u3d_render_loss_step (one call: forward half + backward half) through ctypes; d_head_out starts as `prefill`."""
+    import ctypes
+    import math
+    from unipre3d_amd import _lib
+    from unipre3d_amd.rasterizer import _Plan
+    dev = bd.raw.device
+    B, C, P = bd.raw.shape
+    V = bd.world_view.shape[1]
+    NV = B * V
+    t = math.tan(bd.fov_deg * math.pi / 360)
+    plan = _Plan(B, V, P, H, W, t, t, 1.0, 1, 4, flags)
+    hd = _lib.HeadDesc(1 if level == "object" else 2, C, bd.offset_scale, 0)
+    ld = _lib.LossDesc(_lib.LOSS_KINDS["l2"], 4.0, 1.0)
+    head_out = bd.raw.permute(0, 2, 1).contiguous()
+    u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+    geom, binning, fused_s, bwd = u8(plan.sizes.geom_bytes), u8(plan.sizes.binning_bytes), u8(plan.sizes.fused_bytes), torch.zeros(plan.sizes.backward_bytes, dtype=torch.uint8, device=dev)
+    radii = torch.zeros(NV, P, dtype=torch.int32, device=dev)
+    loss = torch.zeros((), device=dev)
+    d_head = torch.full_like(head_out, prefill)
+    p, c = _lib.ptr, lambda x: x.contiguous()
+    rc = _lib.load().u3d_render_loss_step(ctypes.byref(plan.desc), ctypes.byref(hd), ctypes.byref(ld), p(bd.bg), p(head_out), p(c(bd.center)),
+                                          p(c(bd.world_view).reshape(NV, 16)), p(c(bd.full_proj).reshape(NV, 16)), p(c(bd.camera_center).reshape(NV, 3)),
+                                          p(c(bd.gt).reshape(NV, 3, H, W)), p(None), p(radii), p(loss), p(d_head), p(geom), p(binning), p(fused_s), p(bwd),
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "u3d_render_loss_step")
+    torch.cuda.synchronize()
+    return loss.item(), d_head, geom, plan
+
+
+@pytest.mark.parametrize("P,level", [(6000, "scene"), (3000, "scene"), (6000, "object")])
+def test_sparse_backward_flag_equals_the_dense_chain_rule(P, level):
+    """U3D_FLAG_SPARSE_BWD (ABI 5): the forward half zero-fills d_head_out beside its gradient reduction and lists the Gaussians that
+    received a gradient; the backward half runs the chain rule over that list only.  Same loss and the same d loss / d head_out as the
+    dense chain rule (which visits every Gaussian) -- from a buffer pre-filled with garbage, so every row must have been written by
+    one of the two -- at a size where the flag is honoured (scene-level head, P > 4096) and where it is ignored (small P; object head)."""
+    from unipre3d_amd import _lib, synthetic
+    H, W = 96, 128
+    bd = synthetic.make_batch(2, P, 3, H, W, level=level, seed=23).to(torch.device("cuda:0"))
+    l0, g0, _, _ = _step_via_cabi(bd, H, W, level, _lib.FLAG_ANTIALIASING, 7.0)
+    l1, g1, geom, plan = _step_via_cabi(bd, H, W, level, _lib.FLAG_ANTIALIASING | _lib.FLAG_SPARSE_BWD, -3.0)
+    assert l0 == l1
+    assert torch.equal(g0 == 0, g1 == 0)                                   # the same rows are exact zeros
+    assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-6               # (cross-slice f64 atomics: order-insensitive, not bit-identical)
+    touched_rows = int((g0.abs().sum(dim=-1) > 0).sum().item())
+    assert 0 < touched_rows < 2 * P
+    if level == "scene" and P > 4096:
+        # the list the backward half walked: every touched Gaussian exactly once
+        al = lambda n: ((n + 255) // 256) * 256
+        NG, NV, tot = 3 * 2 * P, 6, 2 * P
+        o = al(4 * NG) + al(8 * NG) + al(16 * NG) + al(16 * NG) + al(8 * NG) + al(4 * NG) + al(4 * NV) + al(4 * ((tot + 31) // 32 + 1))
+        lst = geom[o:o + 8 * tot].view(torch.int32).reshape(tot, 2)
+        cnt = int(geom[o + al(8 * tot):][:4].view(torch.int32).item())
+        ids = (lst[:cnt, 0].long() * P + lst[:cnt, 1].long()).cpu().numpy()
+        assert cnt == len(set(ids.tolist())) and cnt >= touched_rows
+        rows = np.flatnonzero((g0.abs().sum(dim=-1) > 0).reshape(-1).cpu().numpy())
+        assert set(rows.tolist()) <= set(ids.tolist())
+
+
+def test_render_view_entry_points_equal_the_operator_entry_points(oracle_mod):
+    """u3d_render_view_forward / _backward (ABI 5: features_dc / features_rest through two pointers, visibility from the projection
+    kernel, no inverse-depth plane) against u3d_rasterize_forward / _backward on the concatenated SH tensor, through ctypes, for a
+    batched call (2 sets x 3 views) -- bit-identical image and radii, gradients equal (deterministic fixed-order route)."""
+    import ctypes
+    import math
+    from unipre3d_amd import _lib, head, synthetic
+    from unipre3d_amd.rasterizer import _Plan
+    dev = torch.device("cuda:0")
+    B, P, V, H, W = 2, 200, 3, 64, 80
+    bd = synthetic.make_batch(B, P, V, H, W, level="object", seed=31).to(dev)
+    g = synthetic.gaussians_from_batch(bd)
+    NV = B * V
+    t = math.tan(bd.fov_deg * math.pi / 360)
+    plan = _Plan(B, V, P, H, W, t, t, 1.0, 1, 4, _lib.FLAG_ANTIALIASING)
+    p, c = _lib.ptr, lambda x: x.contiguous()
+    shs = c(head.concat_sh(g["features_dc"], g["features_rest"]))
+    dc, rest = c(g["features_dc"]), c(g["features_rest"])
+    cams = (p(c(bd.world_view).reshape(NV, 16)), p(c(bd.full_proj).reshape(NV, 16)), p(c(bd.camera_center).reshape(NV, 3)))
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dcol = torch.randn(NV, 3, H, W, generator=torch.Generator().manual_seed(4)).to(dev)
+    u8 = lambda n: torch.zeros(n, dtype=torch.uint8, device=dev)
+    lib = _lib.load()
+    xyz, op, sc, rot = c(g["xyz"]), c(g["opacity"]), c(g["scaling"]), c(g["rotation"])
+
+    def grads():
+        return {k: torch.full(s, 5.0, device=dev) for k, s in (("xyz", (B, P, 3)), ("m2d", (NV, P, 3)), ("shs", (B, P, 4, 3)), ("dc", (B, P, 1, 3)),
+                                                               ("rest", (B, P, 3, 3)), ("op", (B, P, 1)), ("sc", (B, P, 3)), ("rot", (B, P, 4)))}
+    # operator entry points
+    ca, ia, ra = torch.empty(NV, 3, H, W, device=dev), torch.empty(NV, 1, H, W, device=dev), torch.zeros(NV, P, dtype=torch.int32, device=dev)
+    sa = [u8(plan.sizes.geom_bytes), u8(plan.sizes.binning_bytes), u8(plan.sizes.image_bytes), u8(plan.sizes.backward_bytes)]
+    _lib.check(lib.u3d_rasterize_forward(ctypes.byref(plan.desc), p(bd.bg), p(xyz), p(shs), p(None), p(op), p(sc), p(rot), p(None), *cams, p(ca), p(ia),
+                                         p(ra), p(sa[0]), p(sa[1]), p(sa[2]), stream), "fwd")
+    ga = grads()
+    _lib.check(lib.u3d_rasterize_backward(ctypes.byref(plan.desc), p(bd.bg), p(xyz), p(shs), p(None), p(op), p(sc), p(rot), p(None), *cams, p(ra), p(dcol),
+                                          p(None), p(sa[0]), p(sa[1]), p(sa[2]), p(sa[3]), p(ga["xyz"]), p(ga["m2d"]), p(ga["shs"]), p(None), p(ga["op"]),
+                                          p(ga["sc"]), p(ga["rot"]), p(None), stream), "bwd")
+    # the wrapper-body entry points
+    cb, rb, vb = torch.empty(NV, 3, H, W, device=dev), torch.zeros(NV, P, dtype=torch.int32, device=dev), torch.full((NV, P), 9, dtype=torch.uint8, device=dev)
+    sb = [u8(plan.sizes.geom_bytes), u8(plan.sizes.binning_bytes), u8(plan.sizes.image_bytes), u8(plan.sizes.backward_bytes)]
+    _lib.check(lib.u3d_render_view_forward(ctypes.byref(plan.desc), p(bd.bg), p(xyz), p(dc), p(rest), p(op), p(sc), p(rot), *cams, p(cb), p(rb), p(vb),
+                                           p(sb[0]), p(sb[1]), p(sb[2]), stream), "view fwd")
+    gb = grads()
+    _lib.check(lib.u3d_render_view_backward(ctypes.byref(plan.desc), p(bd.bg), p(xyz), p(dc), p(rest), p(op), p(sc), p(rot), *cams, p(rb), p(dcol),
+                                            p(sb[0]), p(sb[1]), p(sb[2]), p(sb[3]), p(gb["xyz"]), p(gb["m2d"]), p(gb["dc"]), p(gb["rest"]), p(gb["op"]),
+                                            p(gb["sc"]), p(gb["rot"]), stream), "view bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(ca, cb) and torch.equal(ra, rb) and torch.equal(vb.bool(), ra > 0)
+    for k in ("xyz", "m2d", "op", "sc", "rot"):
+        assert torch.equal(ga[k], gb[k]), k
+    assert torch.equal(ga["shs"][:, :, :1], gb["dc"]) and torch.equal(ga["shs"][:, :, 1:], gb["rest"])
+    # degree 0: no features_rest at all
+    plan0 = _Plan(B, V, P, H, W, t, t, 1.0, 0, 1, _lib.FLAG_ANTIALIASING)
+    c0, r0 = torch.empty(NV, 3, H, W, device=dev), torch.zeros(NV, P, dtype=torch.int32, device=dev)
+    _lib.check(lib.u3d_render_view_forward(ctypes.byref(plan0.desc), p(bd.bg), p(xyz), p(dc), p(None), p(op), p(sc), p(rot), *cams, p(c0), p(r0), p(None),
+                                           p(sb[0]), p(sb[1]), p(sb[2]), stream), "view fwd deg 0")
+    c1, i1, r1 = torch.empty_like(c0), torch.empty(NV, 1, H, W, device=dev), torch.zeros_like(r0)
+    _lib.check(lib.u3d_rasterize_forward(ctypes.byref(plan0.desc), p(bd.bg), p(xyz), p(dc), p(None), p(op), p(sc), p(rot), p(None), *cams, p(c1), p(i1),
+                                         p(r1), p(sa[0]), p(sa[1]), p(sa[2]), stream), "fwd deg 0")
+    torch.cuda.synchronize()
+    assert torch.equal(c0, c1) and torch.equal(r0, r1)
+    assert lib.u3d_render_view_forward(ctypes.byref(plan.desc), p(bd.bg), p(xyz), p(dc), p(None), p(op), p(sc), p(rot), *cams, p(cb), p(rb), p(vb),
+                                       p(sb[0]), p(sb[1]), p(sb[2]), stream) == 1          # M = 4 without features_rest: invalid argument

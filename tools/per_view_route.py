@@ -37,10 +37,10 @@ class _NullOp(torch.autograd.Function):
     """Same inputs / outputs as the operator, no kernel: outputs and gradients are uninitialised allocations."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, opacities, scales, rotations):
-        ctx.shapes = [t.shape for t in (means3D, means2D, shs, opacities, scales, rotations)]
-        ctx.dev = means3D.device
-        return torch.empty(3, H, W, device=means3D.device), torch.empty(P, dtype=torch.int32, device=means3D.device)
+    def forward(ctx, *tensors):
+        ctx.shapes = [t.shape for t in tensors]
+        ctx.dev = tensors[0].device
+        return torch.empty(3, H, W, device=ctx.dev), torch.empty(P, dtype=torch.int32, device=ctx.dev)
 
     @staticmethod
     def backward(ctx, g, _):
@@ -51,18 +51,23 @@ def timeit(name, fn, n):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(n):
-        l = fn()
-    torch.cuda.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / n
-    print("%-58s %.2f ms/step  %.0f views/s  %.0f us per forward+backward pair" % (name, ms, B * V / ms * 1e3, 1e3 * ms / (B * V)))
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    ts.sort()
+    ms = sum(ts) / n
+    print("%-58s mean %.2f  min %.2f  median %.2f ms/step  %.0f views/s  %.0f us per forward+backward pair (min)"
+          % (name, ms, ts[0], ts[n // 2], B * V / ts[0] * 1e3, 1e3 * ts[0] / (B * V)))
 
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 timeit("per-view operator loop (reference call pattern)", per_view_step, n)
-real = rasterizer.GaussianRasterizer.forward
-rasterizer.GaussianRasterizer.forward = lambda self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None: \
-    _NullOp.apply(means3D, means2D, shs, opacities, scales, rotations) + (None,)
+prev = rasterizer.set_operator_override(lambda *tensors: _NullOp.apply(*tensors) + (None,))
 timeit("same loop, NO-OP operator (the wrapper's own cost)", per_view_step, n)
-rasterizer.GaussianRasterizer.forward = real
+rasterizer.set_operator_override(prev)
+renderer.FAST_PATH = False
+timeit("per-view loop, op-by-op wrapper body (round 3)", per_view_step, n)
+renderer.FAST_PATH = True

@@ -14,11 +14,13 @@ import subprocess
 import torch  # noqa: F401  (must be imported before the library is opened, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libunipre3d_rasterizer.so")
+# (experiments only: U3D_LIB_DIRNAME selects a kernel-variant build directory made with `make LIBDIR=../lib_x EXTRA=...`)
+LIB_DIR = os.path.join(_HERE, os.environ.get("U3D_LIB_DIRNAME", "lib"))
+LIB_PATH = os.path.join(LIB_DIR, "libunipre3d_rasterizer.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 5   # include/unipre3d_rasterizer.h: U3D_ABI_VERSION
-FLAG_PREFILTERED, FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_EXACT_AA_GRAD, FLAG_STATS, FLAG_ACC_CLEAN = 1, 2, 4, 8, 16, 32
+FLAG_PREFILTERED, FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_EXACT_AA_GRAD, FLAG_STATS, FLAG_ACC_CLEAN, FLAG_SPARSE_BWD = 1, 2, 4, 8, 16, 32, 64
 
 EXPORTS = ("u3d_abi_version", "u3d_error_string", "u3d_scratch_query", "u3d_rasterize_forward",
            "u3d_rasterize_backward", "u3d_mark_visible", "u3d_profile_begin", "u3d_profile_end",
@@ -97,7 +99,7 @@ def load() -> ctypes.CDLL:
     lib.u3d_render_loss_step.restype = ctypes.c_int
     lib.u3d_render_loss_step.argtypes = [ctypes.POINTER(RasterDesc), ctypes.POINTER(HeadDesc), ctypes.POINTER(LossDesc)] + [vp] * 16
     lib.u3d_render_loss_step_forward.restype = ctypes.c_int
-    lib.u3d_render_loss_step_forward.argtypes = [ctypes.POINTER(RasterDesc), ctypes.POINTER(HeadDesc), ctypes.POINTER(LossDesc)] + [vp] * 15
+    lib.u3d_render_loss_step_forward.argtypes = [ctypes.POINTER(RasterDesc), ctypes.POINTER(HeadDesc), ctypes.POINTER(LossDesc)] + [vp] * 16
     lib.u3d_render_loss_step_backward.restype = ctypes.c_int
     lib.u3d_render_loss_step_backward.argtypes = [ctypes.POINTER(RasterDesc), ctypes.POINTER(HeadDesc)] + [vp] * 13
     lib.u3d_render_view_forward.restype = ctypes.c_int

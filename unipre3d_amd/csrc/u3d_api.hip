@@ -448,7 +448,7 @@ int u3d_render_loss_step_forward(const u3d_raster_desc* desc, const u3d_head_des
                                  const float* bg, const float* head_out, const float* center, const float* viewmatrix,
                                  const float* projmatrix, const float* campos, const float* gt, float* out_color,
                                  int32_t* radii, float* loss_out, void* geom, void* binning, void* fused,
-                                 void* backward_scratch, void* stream) {
+                                 void* backward_scratch, float* d_head_out, void* stream) {
   int rc = check_fused(desc, head, loss);
   if (rc != U3D_OK) return rc;
   const u3d_raster_desc& d = *desc;
@@ -482,9 +482,13 @@ int u3d_render_loss_step_forward(const u3d_raster_desc* desc, const u3d_head_des
     u3d_launch_depth_sort(d, b, radii, s);
   }
   const U3DLoss L = make_loss(d, *loss, gt, f.partial, nullptr);
+  // U3D_FLAG_SPARSE_BWD: the gradient buffer is zero-filled beside the gradient reduction and the touched Gaussians are listed
+  const bool sparse = u3d_sparse_bwd(d, head->mode);
+  if (sparse && (!d_head_out || (reinterpret_cast<uintptr_t>(d_head_out) & 15u) != 0u)) return U3D_ERR_INVALID_ARGUMENT;
   {
     ProfScope ps(5, s);
-    u3d_launch_render_fb(d, b, bg, out_color, L, acc, part, loss_out, s);   // + partial reduce + loss reduce
+    u3d_launch_render_fb(d, b, bg, out_color, L, acc, part, loss_out, s, sparse ? d_head_out : nullptr,
+                         sparse ? u3d_total_P(d) * (size_t)head->channels : 0, sparse);   // + partial reduce + loss reduce
   }
   return finish(desc, s);
 }
@@ -514,7 +518,8 @@ int u3d_render_loss_step_backward(const u3d_raster_desc* desc, const u3d_head_de
   sink.shs = d_head_out + 11; sink.colors = nullptr; sink.cov = nullptr; sink.means2D = nullptr; sink.qdot = f.qdot;
   {
     ProfScope ps(4, s);
-    u3d_launch_preprocess_bwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, sink, s, acc, dloss);   // reads, then re-zeroes, the touched accumulators
+    u3d_launch_preprocess_bwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, sink, s, acc, dloss,
+                              u3d_sparse_bwd(d, head->mode));   // reads, then re-zeroes, the touched accumulators
   }
   if (head->mode == 1) u3d_launch_quat_fixup(d, head_out + 7, head->channels, f.qnorm, f.qdot, d_head_out + 7, s);
   return finish(desc, s);
@@ -526,7 +531,7 @@ int u3d_render_loss_step(const u3d_raster_desc* desc, const u3d_head_desc* head,
                          float* d_head_out, void* geom, void* binning, void* fused, void* backward_scratch, void* stream) {
   if (!d_head_out) return U3D_ERR_INVALID_ARGUMENT;
   const int rc = u3d_render_loss_step_forward(desc, head, loss, bg, head_out, center, viewmatrix, projmatrix, campos, gt, out_color, radii,
-                                              loss_out, geom, binning, fused, backward_scratch, stream);
+                                              loss_out, geom, binning, fused, backward_scratch, d_head_out, stream);
   if (rc != U3D_OK) return rc;
   return u3d_render_loss_step_backward(desc, head, head_out, center, viewmatrix, projmatrix, campos, radii, nullptr, geom, binning, fused,
                                        backward_scratch, d_head_out, stream);

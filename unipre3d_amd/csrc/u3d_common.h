@@ -43,6 +43,11 @@ struct U3DBuffers {
   // one bit per Gaussian of the call (index gbase + i): some view handed it a gradient.  Cleared by preprocess_fwd, set by the
   // gradient reduction, read by preprocess_bwd's wave triage -- one word per 32 Gaussians instead of 8 bytes per (view, Gaussian)
   uint32_t* touched_words;
+  // scene level (P > U3D_LDS_SORT_MAX): the Gaussians some view handed a gradient, as a LIST -- (set, index within the set) in
+  // arrival order, appended by whoever sets a Gaussian's touched bit first, count cleared by preprocess_fwd.  The chain-rule kernel
+  // of the fused step walks this list (a few thousand entries) instead of all 10^5 Gaussians of a scene (U3D_FLAG_SPARSE_BWD).
+  uint2* touched_list;       // [total_P]
+  uint32_t* touched_count;   // [1]
   // binning
   uint32_t* sorted_id;   // [NV*P] Gaussian index (within the set) in front-to-back order
   uint2* sorted_rect;    // [NV*P] rect of sorted_id[k]
@@ -81,6 +86,14 @@ __device__ __forceinline__ size_t u3d_view_gbase(const U3DSpan& s, int view) {  
 }
 __device__ __forceinline__ void u3d_mark_touched(uint32_t* __restrict__ words, size_t gi) {
   atomicOr(&words[gi >> 5], 1u << (uint32_t)(gi & 31));
+}
+// ... and, the first time a Gaussian's bit goes up, append it to the touched list (one returning atomic per TOUCHED Gaussian and
+// view -- thousands, not the 10^5..10^6 pairs of a launch)
+__device__ __forceinline__ void u3d_mark_touched_list(uint32_t* __restrict__ words, size_t gi, uint2* __restrict__ list,
+                                                      uint32_t* __restrict__ count, uint32_t item, uint32_t local) {
+  const uint32_t bit = 1u << (uint32_t)(gi & 31);
+  const uint32_t old = atomicOr(&words[gi >> 5], bit);
+  if (list && !(old & bit)) list[atomicAdd(count, 1u)] = make_uint2(item, local);
 }
 __device__ __forceinline__ size_t u3d_pair_base(const U3DSpan& s, int vk, int Pi, size_t gbase) {
   return (size_t)s.vpi * gbase + (size_t)vk * Pi;
@@ -193,6 +206,8 @@ static inline U3DLayout u3d_carve(const u3d_raster_desc& d, void* geom, void* bi
   L.num_rendered_offset = o;
   CARVE(g, num_rendered, uint32_t, NV);
   CARVE(g, touched_words, uint32_t, (u3d_total_P(d) + 31) / 32 + 1);
+  CARVE(g, touched_list, uint2, d.P > U3D_LDS_SORT_MAX ? u3d_total_P(d) : 0);
+  CARVE(g, touched_count, uint32_t, 1);
   L.geom_bytes = o > 0 ? o : 256;
   o = 0;
   char* bn = (char*)binning;
@@ -243,7 +258,12 @@ static inline bool u3d_uses_touched_words(const u3d_raster_desc& d) { return d.P
 static inline int u3d_rect_indirect(const u3d_raster_desc& d) { return d.P > U3D_LDS_SORT_MAX ? 1 : 0; }
 void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, const int32_t* radii, const double* acc,
-                               const U3DGradSink& sink, hipStream_t s, double* acc_reset = nullptr, const float* gscale = nullptr);
+                               const U3DGradSink& sink, hipStream_t s, double* acc_reset = nullptr, const float* gscale = nullptr,
+                               bool sparse = false);
+// U3D_FLAG_SPARSE_BWD is honoured for the scene-level head at scene-level sizes only (what the touched list exists for)
+static inline bool u3d_sparse_bwd(const u3d_raster_desc& d, int head_mode) {
+  return (d.flags & U3D_FLAG_SPARSE_BWD) != 0 && head_mode == 2 && d.P > U3D_LDS_SORT_MAX;
+}
 // true when preprocess_fwd also produces the per-view depth order (P <= 256): skip u3d_launch_depth_sort then
 bool u3d_preprocess_sorts(const u3d_raster_desc& d);
 void u3d_launch_quat_norms(const u3d_raster_desc& d, const float* rots, int s_rots, float* qnorm, float* qdot_zero, hipStream_t s);
@@ -256,7 +276,8 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
                            const float* dL_dinvdepth, const float* out_color, const U3DLoss& loss, double* acc,
                            float* part, hipStream_t s);
 void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,
-                          const U3DLoss& loss, double* acc, float* part, float* loss_out, hipStream_t s);
+                          const U3DLoss& loss, double* acc, float* part, float* loss_out, hipStream_t s,
+                          float* zero_fill = nullptr, size_t zero_floats = 0, bool list_touched = false);
 void u3d_launch_loss_reduce(int n, const float* partial, float inv_count, float* loss_out, hipStream_t s);
 
 #ifdef __HIPCC__

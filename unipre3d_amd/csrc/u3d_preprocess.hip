@@ -131,7 +131,8 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     float4* __restrict__ rgbd, uint2* __restrict__ rect, uint32_t* __restrict__ clamped,
     uint32_t* __restrict__ num_rendered, double* __restrict__ acc_zero, size_t NG, uint32_t* __restrict__ sorted_id,
     uint2* __restrict__ sorted_rect, uint32_t* __restrict__ n_vis, uint32_t* __restrict__ msd_total, int msd_bins,
-    uint32_t* __restrict__ touched_words, uint8_t* __restrict__ visible) {
+    uint32_t* __restrict__ touched_words, uint8_t* __restrict__ visible, uint32_t* __restrict__ touched_count) {
+  if (touched_count && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *touched_count = 0u;   // (the touched list restarts)
   // (msd_total != null: P > 4096; the depth sort that follows partitions by depth bucket with one global atomic per (workgroup,
   // bucket) on these per-view totals -- the first workgroup of every (set, view slice) clears them here instead of a memset node)
   if (msd_total && blockIdx.x == 0) {
@@ -344,7 +345,8 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     U3DSpan span, int vpi, int M, int H, int W, float tanx, float tany, float mod, int flags, size_t NG, U3DSource src,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const double* acc, double* acc_reset,
-    U3DGradSink sink, const float* __restrict__ gscale, const uint32_t* __restrict__ touched_words) {
+    U3DGradSink sink, const float* __restrict__ gscale, const uint32_t* __restrict__ touched_words,
+    const uint2* __restrict__ sparse_list, const uint32_t* __restrict__ sparse_count) {
 #pragma clang fp contract(fast)
   // gscale: device scalar dL/dloss of the fused step (autograd's grad_output) or null (= 1).  Every output of this kernel -- and the
   // column dot products quat_fixup finishes -- is linear in the accumulators, so scaling them as they are read IS the d_head * g
@@ -352,14 +354,24 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
   const float gs = gscale ? gscale[0] : 1.f;
   // 4 consecutive lanes (a DPP quad) share one Gaussian and split its views: lane&3 = view slot
   __shared__ float s_qdot[4][4];
-  const int item = blockIdx.y;
+  // sparse mode (U3D_FLAG_SPARSE_BWD, scene level): the quad's Gaussian comes from the touched list the gradient reduction
+  // appended to -- (set, index) in arrival order; the rows of every other Gaussian were zero-filled by the forward half and a
+  // workgroup beyond the end of the list leaves at once
+  int item = blockIdx.y, i = blockIdx.x * (U3D_BLOCK / 4) + (threadIdx.x >> 2);
+  bool listed = true;
+  if (sparse_list) {
+    const uint32_t n = *sparse_count;
+    if ((uint32_t)(blockIdx.x * (U3D_BLOCK / 4)) >= n) return;
+    listed = (uint32_t)i < n;
+    const uint2 e = sparse_list[listed ? i : 0];
+    item = (int)e.x; i = (int)e.y;
+  }
   int P;
   size_t gbase;
   u3d_set_span(span, item, P, gbase);
   const size_t pbase0 = u3d_pair_base(span, 0, P, gbase);   // pairs of (this set, view slot vk): pbase0 + vk * P + i
   const int vslot = threadIdx.x & 3;
-  const int i = blockIdx.x * (U3D_BLOCK / 4) + (threadIdx.x >> 2);
-  const bool alive = i < P;
+  const bool alive = listed && i < P;
   const size_t gi = gbase + (alive ? i : 0);
   constexpr int K = (D + 1) * (D + 1);
   const bool writer = alive && vslot == 0;
@@ -368,10 +380,10 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
   // of the view's 10^5 sorted entries): such a wave writes its zeros and skips the parameter loads, the activations and Sigma.
   // (Only asked for at scene level, U3D_FLAG_INTERNAL_TRIAGE: at object level every Gaussian is live and the extra dependent
   // load phase costs this latency-bound kernel ~1 us.)
-  bool lane_live = (flags & U3D_FLAG_INTERNAL_TRIAGE) == 0;
+  bool lane_live = (flags & U3D_FLAG_INTERNAL_TRIAGE) == 0 || (sparse_list != nullptr && alive);
   // scene level, fused mode: the block first clears ITS 64 rows of d(head output) with full-width stores (64 x C consecutive floats),
   // then only the waves that own a touched Gaussian compute anything; a row-by-row zero fill from each idle wave ran at ~1 TB/s
-  const bool block_zero = !lane_live && src.act != 0;
+  const bool block_zero = !sparse_list && !lane_live && src.act != 0;
   if (block_zero) {
     const int C = src.s_means, ib = blockIdx.x * (U3D_BLOCK / 4), rows = min(U3D_BLOCK / 4, P - ib);
     if (rows > 0) {
@@ -387,7 +399,8 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     }
     __syncthreads();   // (the rows a live wave writes below belong to this block)
   }
-  if (!lane_live) lane_live = alive && ((touched_words[gi >> 5] >> (uint32_t)(gi & 31)) & 1u) != 0u;   // one word per 32 Gaussians
+  if (!lane_live && !sparse_list) lane_live = alive && ((touched_words[gi >> 5] >> (uint32_t)(gi & 31)) & 1u) != 0u;   // one word per 32 Gaussians
+  if (sparse_list && __ballot(lane_live) == 0ull) return;      // (a wave past the end of the list: its rows are already zero)
   if (__ballot(lane_live) == 0ull) {
     if (sink.means2D) {
       for (int vk = vslot; vk < (alive ? vpi : 0); vk += 4) {
@@ -811,7 +824,8 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
                      d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, d.flags, src, viewmatrix, projmatrix, campos, \
                      radii, b.depth, b.xy, b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered, acc_zero, NG,               \
                      fuse_sort ? b.sorted_id : nullptr, b.sorted_rect, b.n_vis, d.P > U3D_LDS_SORT_MAX ? b.sort_hist : nullptr, u3d_msd_bins(d.P), \
-                     u3d_uses_touched_words(d) ? b.touched_words : nullptr, visible)
+                     u3d_uses_touched_words(d) ? b.touched_words : nullptr, visible,                                      \
+                     u3d_uses_touched_words(d) ? b.touched_count : nullptr)
   switch (D) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;
@@ -823,15 +837,20 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 
 void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,
                                const float* projmatrix, const float* campos, const int32_t* radii, const double* acc,
-                               const U3DGradSink& sink, hipStream_t s, double* acc_reset, const float* gscale) {
+                               const U3DGradSink& sink, hipStream_t s, double* acc_reset, const float* gscale, bool sparse) {
   const size_t NG = (size_t)d.views_per_item * u3d_total_P(d);
   dim3 grid((d.P + U3D_BLOCK / 4 - 1) / (U3D_BLOCK / 4), d.n_items), block(U3D_BLOCK);
+  // sparse: one linear grid over the touched list, sized for the worst case (every Gaussian touched); workgroups past the
+  // device-side count leave at once
+  if (sparse) grid = dim3((unsigned)((u3d_total_P(d) + U3D_BLOCK / 4 - 1) / (U3D_BLOCK / 4)), 1);
   const int D = src.shs ? d.sh_degree : 0;
   const int flags = d.flags | (d.P > U3D_LDS_SORT_MAX ? U3D_FLAG_INTERNAL_TRIAGE : 0);   // scene level: most waves only write zeros
+  const uint2* sl = sparse ? b.touched_list : nullptr;
+  const uint32_t* sc = sparse ? b.touched_count : nullptr;
 #define LAUNCH(DEG)                                                                                                    \
   hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, u3d_span(d), d.views_per_item, d.sh_coeffs, d.image_height, \
                      d.image_width, d.tanfovx, d.tanfovy, d.scale_modifier, flags, NG, src, viewmatrix, projmatrix,    \
-                     campos, radii, b.clamped, acc, acc_reset, sink, gscale, b.touched_words)
+                     campos, radii, b.clamped, acc, acc_reset, sink, gscale, b.touched_words, sl, sc)
   switch (D) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;

@@ -127,6 +127,9 @@ struct TileGeom {
   uint32_t* touched;   // the `clamped` words (U3D_TOUCHED_BIT), backward only
   uint32_t* tw;        // per-Gaussian touched bitmap (scene level only, else null) and the first Gaussian of the view's set
   size_t gbase;
+  uint2* tlist;        // touched list + count (U3D_FLAG_SPARSE_BWD, else null) and the view's set
+  uint32_t* tcount;
+  uint32_t item;
 };
 
 // stage sorted entries [b*64, b*64+64) limited to `limit`; returns the hit ballot (compaction keeps the order).
@@ -446,7 +449,7 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
         }
         if (nz) {
           G.touched[g] |= U3D_TOUCHED_BIT;   // (every writer ORs the same bit into an otherwise constant word)
-          if (G.tw) u3d_mark_touched(G.tw, G.gbase + (g - G.vbase));
+          if (G.tw) u3d_mark_touched_list(G.tw, G.gbase + (g - G.vbase), G.tlist, G.tcount, G.item, (uint32_t)(g - G.vbase));
         }
       }
     } else {
@@ -526,7 +529,8 @@ static_assert(TILE_WAVES == 1, "one wave = one workgroup = one tile");
   int Pv_;        /* Gaussians of this view's set; first (view, Gaussian) pair (uniform batch: view * P, no division) */ \
   size_t vb_;                                                                                            \
   u3d_view_span(span, view, Pv_, vb_);                                                                   \
-  const TileGeom G{sorted_id, sorted_rect, xy, conic_op, rgbd, vb_, tx, ty, rect_indirect, touched, touched_words, touched_words ? u3d_view_gbase(span, view) : 0}
+  const TileGeom G{sorted_id, sorted_rect, xy, conic_op, rgbd, vb_, tx, ty, rect_indirect, touched, touched_words, touched_words ? u3d_view_gbase(span, view) : 0, \
+                   tlist, tcount, (uint32_t)(view / span.vpi)}
 
 // ---- forward (operator path): colour, inverse depth, and the state the backward kernel restarts from --------
 // DEPTH = false: the caller drops the inverse-depth output (the reference does: `rendered_image, radii, _ = rasterizer(...)`,
@@ -540,6 +544,8 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last, U3DLoss loss) {
   uint32_t* const touched = nullptr;
   uint32_t* const touched_words = nullptr;
+  uint2* const tlist = nullptr;
+  uint32_t* const tcount = nullptr;
   __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ float sD[TILE_WAVES][DEPTH ? U3D_WAVE : 1];
@@ -587,6 +593,8 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
     const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_last, double* __restrict__ acc,
     float* __restrict__ part, const float* __restrict__ out_color, uint32_t* __restrict__ touched, uint32_t* __restrict__ touched_words,
     U3DLoss loss) {
+  uint2* const tlist = nullptr;          // (the list is the fused step's: U3D_FLAG_SPARSE_BWD)
+  uint32_t* const tcount = nullptr;
   __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ float sD[TILE_WAVES][HAS_INVD ? U3D_WAVE : 1];
@@ -659,7 +667,8 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, int rect_indirect, const uint32_t* __restrict__ n_vis,
     const float2* __restrict__ xy, const float4* __restrict__ conic_op, const float4* __restrict__ rgbd,
     const float* __restrict__ bg, float* __restrict__ out_color, double* __restrict__ acc, float* __restrict__ part,
-    uint32_t* __restrict__ touched, uint32_t* __restrict__ touched_words, U3DLoss loss) {
+    uint32_t* __restrict__ touched, uint32_t* __restrict__ touched_words, uint2* __restrict__ tlist, uint32_t* __restrict__ tcount,
+    U3DLoss loss) {
   __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ __attribute__((aligned(8))) float sAcc[TILE_WAVES][U3D_WAVE][10];
@@ -729,9 +738,21 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(U3DSpan span
                                                                    double* __restrict__ acc, uint32_t* __restrict__ touched,
                                                                    uint32_t* __restrict__ touched_words, int n_loss,
                                                                    const float* __restrict__ loss_partial, float inv_count,
-                                                                   float* __restrict__ loss_out) {
+                                                                   float* __restrict__ loss_out, uint2* __restrict__ tlist,
+                                                                   uint32_t* __restrict__ tcount, float* __restrict__ zero_fill,
+                                                                   size_t zero_floats) {
   __shared__ double s_sum[U3D_WAVE][10];
   __shared__ uint32_t s_cmax;
+  if ((int)blockIdx.y > nsplit) {
+    // rows beyond the loss row (U3D_FLAG_SPARSE_BWD): zero-fill the gradient buffer the backward half will scatter into -- 16-byte
+    // stores from workgroups that run beside the latency-bound tile chains of the reduction, i.e. off the step's critical path
+    const size_t nb = (size_t)gridDim.x * (gridDim.y - nsplit - 1), bid = (size_t)(blockIdx.y - nsplit - 1) * gridDim.x + blockIdx.x;
+    const size_t n4 = zero_floats >> 2;
+    float4* z4 = reinterpret_cast<float4*>(zero_fill);
+    for (size_t e = bid * REDUCE_THREADS + threadIdx.x; e < n4; e += nb * REDUCE_THREADS) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bid == 0 && threadIdx.x < (zero_floats & 3)) zero_fill[(n4 << 2) + threadIdx.x] = 0.f;
+    return;
+  }
   if ((int)blockIdx.y == nsplit) {
     // extra row of the grid: fixed-order sum of the per-tile loss partials (replaces a separate launch)
     if (blockIdx.x != 0) return;
@@ -823,7 +844,8 @@ __global__ __launch_bounds__(REDUCE_THREADS) void bwd_reduce_kernel(U3DSpan span
         if (outv != 0.0) unsafeAtomicAdd(&acc[(size_t)k * NG + g], outv);
         if (k == 0) {
           touched[g] |= U3D_TOUCHED_BIT;   // this (view, Gaussian) has a non-zero row
-          if (touched_words) u3d_mark_touched(touched_words, u3d_view_gbase(span, view) + (g - vb));
+          if (touched_words)
+            u3d_mark_touched_list(touched_words, u3d_view_gbase(span, view) + (g - vb), tlist, tcount, (uint32_t)(view / span.vpi), (uint32_t)(g - vb));
         }
       }
     }
@@ -981,7 +1003,8 @@ void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
 }
 
 void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,
-                          const U3DLoss& loss, double* acc, float* part, float* loss_out, hipStream_t s) {
+                          const U3DLoss& loss, double* acc, float* part, float* loss_out, hipStream_t s,
+                          float* zero_fill, size_t zero_floats, bool list_touched) {
   const int tiles_x = (d.image_width + U3D_TILE - 1) / U3D_TILE, tiles_y = (d.image_height + U3D_TILE - 1) / U3D_TILE;
   const int T = tiles_x * tiles_y;
   const uint32_t ntiles = (uint32_t)(d.n_items * d.views_per_item * T);
@@ -989,20 +1012,36 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
   if (ntiles == 0 || NG == 0) return;
   const TileGrid tg = tile_grid(d, tiles_x, T);
   uint32_t* tw = u3d_uses_touched_words(d) ? b.touched_words : nullptr;
+  uint2* tl = (list_touched && tw) ? b.touched_list : nullptr;
+  uint32_t* tc = (list_touched && tw) ? b.touched_count : nullptr;
   if (u3d_part_blocks(d) == 1)
     hipLaunchKernelGGL(render_fb_wave_kernel<1>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height, d.image_width,
                        tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, u3d_rect_indirect(d) ? b.rect : b.sorted_rect, u3d_rect_indirect(d), b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
-                       acc, part, b.clamped, tw, loss);
+                       acc, part, b.clamped, tw, tl, tc, loss);
   else
     hipLaunchKernelGGL(render_fb_wave_kernel<U3D_PART_BLOCKS>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height,
                        d.image_width, tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, u3d_rect_indirect(d) ? b.rect : b.sorted_rect, u3d_rect_indirect(d), b.n_vis, b.xy, b.conic_op, b.rgbd, bg,
-                       out_color, acc, part, b.clamped, tw, loss);
+                       out_color, acc, part, b.clamped, tw, tl, tc, loss);
   const int nsplit = bwd_reduce_split(T, d.n_items * d.views_per_item);
-  auto* reduce_k = u3d_part_blocks(d) == 1 ? bwd_reduce1_kernel : bwd_reduce_kernel<U3D_PART_BLOCKS>;
-  hipLaunchKernelGGL(reduce_k, dim3(d.n_items * d.views_per_item, nsplit + 1), dim3(REDUCE_THREADS), 0, s,
-                     u3d_span(d), T, U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id, b.conic_op, part,
-                     reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, tw, (int)ntiles, loss.partial,
-                     loss.inv_count, loss_out);
+  const int NVi = d.n_items * d.views_per_item;
+  if (u3d_part_blocks(d) == 1) {
+    hipLaunchKernelGGL(bwd_reduce1_kernel, dim3(NVi, nsplit + 1), dim3(REDUCE_THREADS), 0, s,
+                       u3d_span(d), T, U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id, b.conic_op, part,
+                       reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, tw, (int)ntiles, loss.partial,
+                       loss.inv_count, loss_out);
+  } else {
+    // zero-fill rows (U3D_FLAG_SPARSE_BWD): ~256 extra workgroups of 640 threads, at most one per 64 KB to fill
+    int zrows = 0;
+    if (zero_fill && zero_floats > 0) {
+      const size_t want = (zero_floats * sizeof(float) + 65535) / 65536;
+      zrows = (int)((want < 256 ? want : 256) + (size_t)NVi - 1) / NVi;
+      if (zrows < 1) zrows = 1;
+    }
+    hipLaunchKernelGGL(bwd_reduce_kernel<U3D_PART_BLOCKS>, dim3(NVi, nsplit + 1 + zrows), dim3(REDUCE_THREADS), 0, s,
+                       u3d_span(d), T, U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id, b.conic_op, part,
+                       reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, tw, (int)ntiles, loss.partial,
+                       loss.inv_count, loss_out, tl, tc, zero_fill, zero_floats);
+  }
 }
 
 void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, const float* dL_dcolor,
@@ -1024,9 +1063,14 @@ void u3d_launch_render_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const 
   else { if (invd) LAUNCH(true, U3D_PART_BLOCKS); else LAUNCH(false, U3D_PART_BLOCKS); }
 #undef LAUNCH
   const int nsplit = bwd_reduce_split(T, d.n_items * d.views_per_item);
-  auto* reduce_k = u3d_part_blocks(d) == 1 ? bwd_reduce1_kernel : bwd_reduce_kernel<U3D_PART_BLOCKS>;
-  hipLaunchKernelGGL(reduce_k, dim3(d.n_items * d.views_per_item, nsplit), dim3(REDUCE_THREADS), 0, s,
-                     u3d_span(d), T, invd ? U3D_NACC : U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id,
-                     b.conic_op, part, reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, tw, 0, nullptr, 0.f,
-                     nullptr);
+  if (u3d_part_blocks(d) == 1)
+    hipLaunchKernelGGL(bwd_reduce1_kernel, dim3(d.n_items * d.views_per_item, nsplit), dim3(REDUCE_THREADS), 0, s,
+                       u3d_span(d), T, invd ? U3D_NACC : U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id,
+                       b.conic_op, part, reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, tw, 0, nullptr, 0.f,
+                       nullptr);
+  else
+    hipLaunchKernelGGL(bwd_reduce_kernel<U3D_PART_BLOCKS>, dim3(d.n_items * d.views_per_item, nsplit), dim3(REDUCE_THREADS), 0, s,
+                       u3d_span(d), T, invd ? U3D_NACC : U3D_NACC - 1, nsplit, NG, 0.5f * (float)d.image_width, 0.5f * (float)d.image_height, b.sorted_id,
+                       b.conic_op, part, reinterpret_cast<const uint32_t*>(part + (size_t)ntiles * BWD_PART_STRIDE), acc, b.clamped, tw, 0, nullptr, 0.f,
+                       nullptr, (uint2*)nullptr, (uint32_t*)nullptr, (float*)nullptr, (size_t)0);
 }

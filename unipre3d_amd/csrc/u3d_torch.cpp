@@ -428,7 +428,7 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
     u3d_raster_desc d{};
     d.n_items = (int32_t)B; d.views_per_item = (int32_t)V; d.P = (int32_t)P; d.image_height = (int32_t)H; d.image_width = (int32_t)W;
     d.tanfovx = d.tanfovy = (float)tanfov; d.scale_modifier = (float)scale_modifier; d.sh_degree = (int32_t)sh_degree;
-    d.sh_coeffs = (int32_t)K; d.flags = (int32_t)flags; d.total_P = (int32_t)total_P;
+    d.sh_coeffs = (int32_t)K; d.flags = (int32_t)flags | (mode == 2 ? U3D_FLAG_SPARSE_BWD : 0); d.total_P = (int32_t)total_P;
     d.item_offsets = ragged ? offsets.data_ptr<int32_t>() : nullptr;
     const Plan plan = plan_for(d);
     u3d_head_desc hd{(int32_t)mode, (int32_t)C, (float)offset_scale, isotropic ? 1 : 0};
@@ -446,9 +446,15 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
     const Lease lease = workspace_acquire(key, plan, shape_key, fopt.dtype(at::kByte));
     u3d_raster_desc dd = d;
     if (lease.clean) dd.flags |= U3D_FLAG_ACC_CLEAN;
+    // scene-level head: the gradient buffer exists before the backward half (U3D_FLAG_SPARSE_BWD, set in `d` by the caller below):
+    // the forward half zero-fills it beside its gradient reduction and the backward half visits the touched Gaussians only.  The
+    // library honours the flag at scene-level sizes; below them the backward half writes every row itself, as before.
+    // (ragged: from zeros, so that rows a malformed prefix-sum table leaves out read as zero gradient whichever route runs)
+    Tensor d_head = (d.flags & U3D_FLAG_SPARSE_BWD) ? (ragged ? at::zeros_like(head_out) : at::empty_like(head_out)) : Tensor();
     const int rc = u3d_render_loss_step_forward(&dd, &hd, &ld, fptr(bg), fptr(head_out), fptr(center), fptr(view), fptr(proj), fptr(campos),
                                                 fptr(gt), want_color ? color.data_ptr<float>() : nullptr, radii.data_ptr<int32_t>(),
-                                                loss.data_ptr<float>(), base, base + plan.o_binning, base + o_fused, lease.buf.data_ptr(), stream);
+                                                loss.data_ptr<float>(), base, base + plan.o_binning, base + o_fused, lease.buf.data_ptr(),
+                                                d_head.defined() ? d_head.data_ptr<float>() : nullptr, stream);
     if (rc != U3D_OK) workspace_release(key, lease.ticket, shape_key, false);
     TORCH_CHECK(rc == U3D_OK, "u3d_render_loss_step_forward failed: ", u3d_error_string(rc), " (code ", rc, ")");
     // (the lease stays outstanding until the backward half has consumed -- and re-zeroed -- the accumulators)
@@ -459,7 +465,7 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
     ctx->saved_data["stream"] = (int64_t)(intptr_t)stream;
     ctx->saved_data["consumed"] = false;
     ctx->saved_data["loss"] = std::vector<double>{(double)loss_kind, non_bg_rate, bg_rate};
-    ctx->save_for_backward({head_out, center, view, proj, campos, radii, arena, lease.buf, offsets, gt, bg});
+    ctx->save_for_backward({head_out, center, view, proj, campos, radii, arena, lease.buf, offsets, gt, bg, d_head});
     ctx->mark_non_differentiable({color, radii});
     ctx->set_materialize_grads(false);
     return {loss, color, radii};
@@ -473,6 +479,7 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
     const Tensor &head_out = sv[0], &center = sv[1], &view = sv[2], &proj = sv[3], &campos = sv[4], &radii = sv[5], &arena = sv[6],
                  &offsets = sv[8], &gt = sv[9], &bg = sv[10];
     Tensor scratch = sv[7];
+    Tensor d_head_pre = sv[11];            // (U3D_FLAG_SPARSE_BWD: zero-filled by the forward half; used by ONE backward)
     const c10::Device dev = head_out.device();
     const WsKey key{(int)dev.index(), (void*)(intptr_t)ctx->saved_data["stream"].toInt()};
     const std::string shape_key = desc_key(plan.d);
@@ -502,9 +509,11 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
       u3d_raster_desc d2 = dd;
       if (lease.clean) d2.flags |= U3D_FLAG_ACC_CLEAN;
       Tensor loss_again = at::empty({}, at::TensorOptions().dtype(at::kFloat).device(dev));
+      if (d_head_pre.defined()) d_head_pre = offsets.defined() ? at::zeros_like(head_out) : at::empty_like(head_out);   // (the first backward handed its buffer to autograd)
       const int rc2 = u3d_render_loss_step_forward(&d2, &hd, &ld, fptr(bg), fptr(head_out), fptr(center), fptr(view), fptr(proj), fptr(campos),
                                                    fptr(gt), nullptr, radii.data_ptr<int32_t>(), loss_again.data_ptr<float>(), (void*)base,
-                                                   (void*)(base + plan.o_binning), (void*)(base + plan.o_image), lease.buf.data_ptr(), stream);
+                                                   (void*)(base + plan.o_binning), (void*)(base + plan.o_image), lease.buf.data_ptr(),
+                                                   d_head_pre.defined() ? d_head_pre.data_ptr<float>() : nullptr, stream);
       if (rc2 != U3D_OK) workspace_release(key, lease.ticket, shape_key, false);
       TORCH_CHECK(rc2 == U3D_OK, "u3d_render_loss_step_forward (recompute) failed: ", u3d_error_string(rc2), " (code ", rc2, ")");
       scratch = lease.buf;
@@ -528,7 +537,7 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
     }
     // (every row is written by the projection-backward kernel; a ragged batch starts from zeros so that rows a malformed prefix-sum
     // table leaves out read as zero gradient instead of as uninitialised memory)
-    Tensor d_head = offsets.defined() ? at::zeros_like(head_out) : at::empty_like(head_out);
+    Tensor d_head = d_head_pre.defined() ? d_head_pre : (offsets.defined() ? at::zeros_like(head_out) : at::empty_like(head_out));
     const int rc = u3d_render_loss_step_backward(&dd, &hd, fptr(head_out), fptr(center), fptr(view), fptr(proj), fptr(campos),
                                                  radii.data_ptr<int32_t>(), gptr, base, base + plan.o_binning, (void*)(base + plan.o_image),
                                                  scratch.data_ptr(), d_head.data_ptr<float>(), stream);

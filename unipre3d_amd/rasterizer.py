@@ -138,7 +138,7 @@ def _stream_ptr(dev=None):
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_BINDING_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "_u3d_torch.so")
+_BINDING_PATH = os.path.join(_lib.LIB_DIR, "_u3d_torch.so")
 _binding = None
 
 
