@@ -470,6 +470,12 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     // trips -- triage word, flags, accumulators, camera -- not arithmetic: the accumulators of an untouched pair are zero anyway)
     const uint32_t cbits = clamped[g];
     const int32_t rad = radii[g];
+    // scene level: this kernel is bound by the 80 B of f64 accumulators per (view, Gaussian) of every live Gaussian, most of whose
+    // views never touched it -- decide first, then fetch the accumulators of the touched pairs only (one more dependent round trip)
+    if ((flags & U3D_FLAG_INTERNAL_TRIAGE) && !(rad > 0 && (cbits & U3D_TOUCHED_BIT) != 0u)) {
+      if (dL_dmeans2D) { dL_dmeans2D[g * 3] = 0.f; dL_dmeans2D[g * 3 + 1] = 0.f; dL_dmeans2D[g * 3 + 2] = 0.f; }
+      continue;
+    }
     double av[U3D_NACC];
 #pragma unroll
     for (int k = 0; k < U3D_NACC; ++k) av[k] = acc[(size_t)k * NG + g];

@@ -72,6 +72,16 @@ __device__ __forceinline__ float mask_sel0(lanemask_t m, float a) {   // lane in
   asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(m));
   return r;
 }
+// m = a & b (NOT_B: a & ~b);  acc |= m;  returns lane in m ? v : 0.
+// (Round 4 tried forming the combined mask IN vcc and selecting with the VOP2 v_cndmask that reads vcc -- 2-cycle class in isolation
+// against 4 for the VOP3 form on an SGPR pair: the scalar write -> vector read of vcc serialises each pixel's chain, render_fb at C2
+// 191.5 -> 198.5 us, compact 641 -> 682 us; EXPERIMENTS.md.)
+template <bool NOT_B>
+__device__ __forceinline__ float mask_combine_sel0(lanemask_t a, lanemask_t b, lanemask_t& acc, float v) {
+  const lanemask_t m = NOT_B ? (a & ~b) : (a & b);
+  acc |= m;
+  return mask_sel0(m, v);
+}
 __device__ __forceinline__ float mask_sel(lanemask_t m, float a, float b) {   // lane in m ? a : b
   float r;
   asm("v_cndmask_b32_e64 %0, %2, %1, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
@@ -218,15 +228,13 @@ __device__ __forceinline__ bool tile_forward(const TileLds& L, const TileGeom& G
         const float w = alpha * F.Tr[k];
         const float test_T = F.Tr[k] - w;          // T (1 - alpha)
         const lanemask_t m_lt = __builtin_amdgcn_fcmpf(test_T, T_STOP, U3D_FCMP_OLT);
-        const lanemask_t m_c = m_ok & ~m_lt;
         m_stop[k] = m_ok & m_lt;
-        const float we = mask_sel0(m_c, w);      // blended weight, 0 for pixels that skip this Gaussian
+        const float we = mask_combine_sel0<true>(m_ok, m_lt, contrib, w);   // blended weight (m_ok & ~m_lt), 0 for pixels that skip this Gaussian
         F.C0[k] = fmaf(Q.z, we, F.C0[k]);
         F.C1[k] = fmaf(Q.w, we, F.C1[k]);
         F.C2[k] = fmaf(R.x, we, F.C2[k]);
         if (DEPTH) F.Dv[k] = fmaf(invd, we, F.Dv[k]);
         F.Tr[k] -= we;
-        contrib |= m_c;
         stopped |= m_stop[k];
       }
       if (contrib != 0ull) { jlast = j; blast = b; }
@@ -306,10 +314,8 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
         dx[k] = A.x - pxf[k];
         const float pw = fmaf(fmaf(A.z, dx[k], bdy), dx[k], cdy2);
         const float araw = Q.y * __builtin_amdgcn_exp2f(pw);   // opacity * G (alpha before the 0.99 clamp)
-        const lanemask_t m = (PLAIN ? ~0ull : __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE)) & __builtin_amdgcn_fcmpf(araw, ALPHA_MIN, U3D_FCMP_OGE) &
-                             __builtin_amdgcn_uicmp(pos, lim[k], U3D_ICMP_ULT);
-        any |= m;
-        ae[k] = mask_sel0(m, araw);
+        const lanemask_t m_a = (PLAIN ? ~0ull : __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE)) & __builtin_amdgcn_fcmpf(araw, ALPHA_MIN, U3D_FCMP_OGE);
+        ae[k] = mask_combine_sel0<false>(m_a, __builtin_amdgcn_uicmp(pos, lim[k], U3D_ICMP_ULT), any, araw);
       }
       if (any == 0ull) continue;
       float m0, mx, mxx, g_r, g_g, g_b, g_d = 0.f;

@@ -19,6 +19,10 @@
 
 #include "unipre3d_rasterizer.h"
 
+#ifndef U3D_BINDING_NO_SPARSE
+#define U3D_BINDING_NO_SPARSE 0   /* experiments: 1 = never ask for U3D_FLAG_SPARSE_BWD */
+#endif
+
 namespace {
 
 using torch::Tensor;
@@ -428,7 +432,7 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
     u3d_raster_desc d{};
     d.n_items = (int32_t)B; d.views_per_item = (int32_t)V; d.P = (int32_t)P; d.image_height = (int32_t)H; d.image_width = (int32_t)W;
     d.tanfovx = d.tanfovy = (float)tanfov; d.scale_modifier = (float)scale_modifier; d.sh_degree = (int32_t)sh_degree;
-    d.sh_coeffs = (int32_t)K; d.flags = (int32_t)flags | (mode == 2 ? U3D_FLAG_SPARSE_BWD : 0); d.total_P = (int32_t)total_P;
+    d.sh_coeffs = (int32_t)K; d.flags = (int32_t)flags | (mode == 2 && !U3D_BINDING_NO_SPARSE ? U3D_FLAG_SPARSE_BWD : 0); d.total_P = (int32_t)total_P;
     d.item_offsets = ragged ? offsets.data_ptr<int32_t>() : nullptr;
     const Plan plan = plan_for(d);
     u3d_head_desc hd{(int32_t)mode, (int32_t)C, (float)offset_scale, isotropic ? 1 : 0};
