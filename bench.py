@@ -560,7 +560,7 @@ def main():
 
     # forward rasterizer alone (north_star: ">= 40 % of the HBM roofline in the forward rasterizer"): the operator's forward
     # kernel (colour + inverse depth + backward state written out) on the same Gaussians, HIP events, outside the timed region
-    fwd_only, fwd_err = None, None
+    fwd_only, fwd_err, fwd_nodepth = None, None, None
     try:
         from unipre3d_amd import head as _head
         from unipre3d_amd.rasterizer import rasterize_gaussians_batched as _rgb
@@ -578,6 +578,31 @@ def main():
                 fwd()
             torch.cuda.synchronize()
             fwd_only = _lib.profile_end()["render_fwd"]
+            # the same forward as the per-view wrapper asks for it (u3d_render_view_forward: SH through two pointers, NO inverse-depth
+            # plane -- the reference drops that output, gaussian_renderer/__init__.py:89), batched over the same views
+            import ctypes
+            from unipre3d_amd.rasterizer import _Plan
+            NVf = B * V
+            plan_f = _Plan(B, V, P, H, W, t_f, t_f, 1.0, 1, 4, _lib.FLAG_ANTIALIASING)
+            u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+            sc_f = (u8(plan_f.sizes.geom_bytes), u8(plan_f.sizes.binning_bytes), u8(plan_f.sizes.image_bytes))
+            col_f, rad_f = torch.empty(NVf, 3, H, W, device=dev), torch.zeros(NVf, P, dtype=torch.int32, device=dev)
+            cc = lambda x: x.contiguous()
+            args_f = [cc(g_f["xyz"]), cc(g_f["features_dc"]), cc(g_f["features_rest"]), cc(g_f["opacity"]), cc(g_f["scaling"]), cc(g_f["rotation"]),
+                      cc(batch.world_view).reshape(NVf, 16), cc(batch.full_proj).reshape(NVf, 16), cc(batch.camera_center).reshape(NVf, 3)]
+            strm = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+            def fwd_nd():
+                _lib.check(_lib.load().u3d_render_view_forward(ctypes.byref(plan_f.desc), _lib.ptr(batch.bg), *[_lib.ptr(x) for x in args_f], _lib.ptr(col_f),
+                                                               _lib.ptr(rad_f), _lib.ptr(None), *[_lib.ptr(x) for x in sc_f], strm), "u3d_render_view_forward")
+            for _ in range(5):
+                fwd_nd()
+            torch.cuda.synchronize()
+            _lib.profile_begin(256, ("render_fwd",))
+            for _ in range(20):
+                fwd_nd()
+            torch.cuda.synchronize()
+            fwd_nodepth = _lib.profile_end()["render_fwd"]
     except Exception as e:  # noqa: BLE001
         fwd_err = repr(e)[:300]
 
@@ -687,7 +712,7 @@ def main():
             fp = _profile_json(f"pmc_traffic_fwd_{prof_cfg}.json") if default_path else None
             real = None
             if fp:
-                real = next((v["hbm_bytes_corrected"] for k, v in fp["per_launch"].items() if "render_fwd" in k), None)
+                real = next((v["hbm_bytes_corrected"] for k, v in fp["per_launch"].items() if "render_fwd" in k and "true" in k), None)
             src_real = f"profiles/{fp['_round'] if fp else PROFILE_ROUND}/pmc_traffic_fwd_{prof_cfg}.json (committed rocprofv3 --pmc passes; NOT measured in this run)"
             if real is None:
                 real, src_real = 24.0 * H * W * NV, "analytic: the 24 B per pixel of outputs the kernel writes (no PMC pass committed for this run's shape)"
@@ -696,6 +721,17 @@ def main():
                                               "reading": "frac_of_8TBs prices SURVEY 8(d)'s algorithmic bytes (40 R + 8 T + 24 HW per view: the contract's "
                                                          "definition, what the >= 40 % target is quoted on); frac_pmc_bytes prices the bytes that really cross "
                                                          "HBM -- this design never materialises the per-instance lists, so it moves ~4 x fewer"})
+            if fwd_nodepth and fwd_nodepth[1]:
+                ms_n = fwd_nodepth[0] / fwd_nodepth[1]
+                real_n = None
+                if fp:
+                    real_n = next((v["hbm_bytes_corrected"] for k, v in fp["per_launch"].items() if "render_fwd" in k and "false" in k), None)
+                out["forward_rasterizer"]["without_inverse_depth"] = {
+                    "avg_ms": ms_n, "frac_of_8TBs": by / 1e9 / (ms_n / 1e3) / HBM_PEAK_GBS,
+                    "real_bytes_per_launch": real_n if real_n is not None else 20.0 * H * W * NV,
+                    "frac_pmc_bytes": (real_n if real_n is not None else 20.0 * H * W * NV) / 1e9 / (ms_n / 1e3) / HBM_PEAK_GBS,
+                    "what": "u3d_render_view_forward (what renderer.render_predicted calls): the tile kernel's variant that does not carry the "
+                            "inverse-depth plane the reference's wrapper drops; same algorithmic bytes as above (SURVEY 8d prices 24 B per pixel)"}
         elif fwd_err:
             out["forward_rasterizer"] = {"error": fwd_err}
         if not a.no_cpu_baseline and world == 1:

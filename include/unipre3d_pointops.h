@@ -34,6 +34,26 @@
 extern "C" {
 #endif
 
+/*
+ * Floating-point contraction of the reference's three-term sums.  `dx*dx + dy*dy + dz*dz` (sampling_gpu.cu:140, ball_query_gpu.cu:38,
+ * interpolate_gpu.cu:40) and `w0*p0 + w1*p1 + w2*p2` (interpolate_gpu.cu:103) are built by nvcc with its default -fmad=true, i.e. as
+ * one rounded product and two fused multiply-adds; WHICH product is the rounded one is the compiler's choice, it changes results in
+ * the last bit, and furthest point sampling turns a last-bit difference into a different index set (ties between equidistant
+ * points).  The reference binary cannot be built here (no nvcc), so the choice is a process-wide mode of this library, each
+ * mode bit-exact against oracle/pointops_oracle.c built the same way:
+ *   U3D_PO_FMA_LLVM   fma(c, c, fma(a, a, b*b))  -- DEFAULT.  NVVM is LLVM: its DAG combiner folds the multiply of the FIRST operand of an
+ *                     fadd into an fma before it looks at the second (visitFADDForFMACombine: "fold (fadd (fmul x, y), z) -> (fma x, y, z)"),
+ *                     so ((a*a + b*b) + c*c) becomes fma(c, c, fma(a, a, b*b)) with b*b the lone rounded product.
+ *   U3D_PO_FMA_CHAIN  fma(c, c, fma(b, b, a*a))  -- the left-to-right reading rounds 1-3 of this build used (first product rounded).
+ *   U3D_PO_NO_FMA     every product rounded, sums left to right: what nvcc emits under -fmad=false.
+ * tests/test_pointops_oracle.py reports on which clouds the three differ (random clouds: FPS never; lattices with exact ties: often).
+ */
+#define U3D_PO_FMA_LLVM 0
+#define U3D_PO_FMA_CHAIN 1
+#define U3D_PO_NO_FMA 2
+int u3d_pointops_set_contraction(int mode); /* 0 ok, 1 unknown mode; applies to the launches that follow */
+int u3d_pointops_get_contraction(void);
+
 int u3d_furthest_point_sampling(int b, int n, int m, const float* points, float* temp, int32_t* idx, void* stream);
 int u3d_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz, int32_t* idx,
                    void* stream);

@@ -20,6 +20,14 @@ def _load():
     return _lib
 
 
+CONTRACTIONS = {"fma_llvm": 0, "fma_chain": 1, "none": 2}
+
+
+def set_contraction(mode):
+    """'fma_llvm' (default) | 'fma_chain' | 'none' -- see include/unipre3d_pointops.h."""
+    _load().po_set_contraction(CONTRACTIONS[mode] if isinstance(mode, str) else int(mode))
+
+
 def _p(a):
     return ctypes.c_void_p(a.ctypes.data)
 

@@ -15,18 +15,29 @@
  * The reference sources are CUDA (no nvcc, no NVIDIA device here) and ship no test vectors, so this restatement is
  * "parity unpinned" against the reference BINARY; it is pinned to the reference SOURCE by construction: the
  * simulated thread loop / shared-memory tree below is the kernel's own control flow executed sequentially.
- * One arithmetic choice is ours: squared distances are evaluated as fmaf(dz,dz,fmaf(dy,dy,dx*dx)) (the contraction
- * nvcc's default -fmad=true most plausibly emits for `dx*dx + dy*dy + dz*dz`); the HIP kernels use the identical
- * expression, so index outputs are compared bit-exactly.
+ * One arithmetic choice cannot be read off the source: how nvcc (-fmad=true) contracts the three-term sums.  All three candidates
+ * are implemented (po_set_contraction; include/unipre3d_pointops.h explains why mode 0, LLVM's combiner order, is the default) and the
+ * HIP kernels are bit-exact against this file in each of them (tests/test_gpu_pointops.py); tests/test_pointops_oracle.py counts
+ * where the modes disagree.
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
+/* a0*a1 + b0*b1 + c0*c1 in the three contractions of include/unipre3d_pointops.h (this file is built -ffp-contract=off, so the
+ * plain products and sums below are rounded one by one): 0 = LLVM / NVVM combiner order, 1 = left-to-right chain, 2 = no fma */
+static int g_mode = 0;
+void po_set_contraction(int mode) { g_mode = mode; }
+int po_get_contraction(void) { return g_mode; }
+static float sum3(float a0, float a1, float b0, float b1, float c0, float c1) {
+  if (g_mode == 0) return fmaf(c0, c1, fmaf(a0, a1, b0 * b1));
+  if (g_mode == 1) return fmaf(c0, c1, fmaf(b0, b1, a0 * a1));
+  return (a0 * a1 + b0 * b1) + c0 * c1;
+}
 static float dist2(const float* a, const float* b) {
   const float dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
-  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  return sum3(dx, dx, dy, dy, dz, dz);
 }
 
 /* cuda_utils.h:10-14 */
@@ -91,7 +102,7 @@ void po_ball_query(int b, int n, int m, float radius, int nsample, const float* 
       for (int k = 0; k < n; ++k) {
         /* (new_x - x)^2 + ... : same value as dist2(pts+k, q) term by term */
         const float dx = q[0] - pts[k * 3], dy = q[1] - pts[k * 3 + 1], dz = q[2] - pts[k * 3 + 2];
-        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        const float d2 = sum3(dx, dx, dy, dy, dz, dz);
         if (d2 < radius2) {
           if (cnt == 0)
             for (int l = 0; l < nsample; ++l) o[l] = k;
@@ -152,8 +163,8 @@ void po_three_nn(int b, int n, int m, const float* unknown, const float* known, 
       int besti1 = 0, besti2 = 0, besti3 = 0;
       for (int k = 0; k < m; ++k) {
         const float x = kn[k * 3 + 0], y = kn[k * 3 + 1], z = kn[k * 3 + 2];
-        /* (ux-x)*(ux-x) + (uy-y)*(uy-y) + (uz-z)*(uz-z), contracted left to right like the other distances of this file */
-        const float d = fmaf(uz - z, uz - z, fmaf(uy - y, uy - y, (ux - x) * (ux - x)));
+        /* (ux-x)*(ux-x) + (uy-y)*(uy-y) + (uz-z)*(uz-z), contracted like the other distances of this file */
+        const float d = sum3(ux - x, ux - x, uy - y, uy - y, uz - z, uz - z);
         if (d < best1) {
           best3 = best2; besti3 = besti2;
           best2 = best1; besti2 = besti1;
@@ -172,7 +183,7 @@ void po_three_nn(int b, int n, int m, const float* unknown, const float* known, 
     }
 }
 
-/* interpolate_gpu.cu:84-103 ; weight[0]*p[idx0] + weight[1]*p[idx1] + weight[2]*p[idx2] contracted left to right */
+/* interpolate_gpu.cu:84-103 ; weight[0]*p[idx0] + weight[1]*p[idx1] + weight[2]*p[idx2] in the selected contraction */
 void po_three_interpolate(int b, int c, int m, int n, const float* points, const int* idx, const float* weight, float* out) {
   for (int bi = 0; bi < b; ++bi)
     for (int ci = 0; ci < c; ++ci)
@@ -180,7 +191,7 @@ void po_three_interpolate(int b, int c, int m, int n, const float* points, const
         const float* w = weight + ((size_t)bi * n + p) * 3;
         const int* ix = idx + ((size_t)bi * n + p) * 3;
         const float* row = points + ((size_t)bi * c + ci) * m;
-        out[((size_t)bi * c + ci) * n + p] = fmaf(w[2], row[ix[2]], fmaf(w[1], row[ix[1]], w[0] * row[ix[0]]));
+        out[((size_t)bi * c + ci) * n + p] = sum3(w[0], row[ix[0]], w[1], row[ix[1]], w[2], row[ix[2]]);
       }
 }
 

@@ -10,6 +10,18 @@ from test_pointops_oracle import _cloud
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["fma_llvm", "fma_chain", "none"])
+def contraction(request):
+    """Every test of this file runs in each contraction mode of the three-term sums (include/unipre3d_pointops.h): the HIP kernels and
+    the oracle are switched together and must agree bit for bit in all of them -- whichever nvcc would have chosen."""
+    from unipre3d_amd import pointops
+    po.set_contraction(request.param)
+    pointops.set_contraction(request.param)
+    yield request.param
+    po.set_contraction("fma_llvm")
+    pointops.set_contraction("fma_llvm")
+
+
 @pytest.mark.parametrize("B,N,M,grid", [(4, 1024, 128, False), (2, 1000, 100, True), (3, 2048, 512, False), (2, 5000, 64, True),
                                         (1, 9000, 32, False), (2, 17, 17, False), (1, 1, 1, False)])
 def test_fps_bit_exact(B, N, M, grid):

@@ -110,10 +110,10 @@ def test_three_nn_is_the_three_smallest_distance_index_pairs():
         d2, idx = po.three_nn(unk, kn)
         for b in range(2):
             dx = unk[b][:, None, :] - kn[b][None, :, :]
-            # the oracle's own contraction order: fma(dz, dz, fma(dy, dy, dx * dx)) -- evaluated in float64 products rounded per step
+            # the oracle's default contraction order (LLVM's): fma(dz, dz, fma(dx, dx, dy * dy)) -- float64 products rounded per step
             f32 = np.float32
-            t = (dx[..., 0] * dx[..., 0]).astype(f32)
-            t = (dx[..., 1].astype(np.float64) * dx[..., 1] + t).astype(f32)
+            t = (dx[..., 1] * dx[..., 1]).astype(f32)
+            t = (dx[..., 0].astype(np.float64) * dx[..., 0] + t).astype(f32)
             d = (dx[..., 2].astype(np.float64) * dx[..., 2] + t).astype(f32)
             order = np.lexsort((np.arange(77)[None, :].repeat(300, 0), d), axis=1)[:, :3]
             assert np.array_equal(idx[b], order.astype(np.int32))
@@ -141,3 +141,48 @@ def test_three_interpolate_definition_and_grad():
         for k in range(3):
             np.add.at(gref[b], (slice(None), idx[b, :, k]), go[b].astype(np.float64) * w[b, :, k][None, :])
     assert np.allclose(g, gref, rtol=1e-5, atol=1e-5)
+
+
+def test_contraction_modes_and_where_they_differ(capsys):
+    """How nvcc's -fmad=true contracts `dx*dx + dy*dy + dz*dz` cannot be read off the reference source, so the oracle (and the HIP
+    kernels, tests/test_gpu_pointops.py) carry all three candidates.  This test REPORTS on which clouds the index outputs of FPS /
+    ball query / 3-NN differ between them, and pins the structure of the answer: the three forms are different roundings of one sum
+    (squared distances agree to 2 ulp), random clouds without exact ties give the same FPS picks in every mode (the arg-max gaps are
+    far larger than an ulp), and a cloud built to sit on a rounding boundary does flip."""
+    modes = ("fma_llvm", "fma_chain", "none")
+    report = []
+    try:
+        for name, xyz, m in (("random 1024", _cloud(2, 1024, 5), 128), ("random 5000", _cloud(1, 5000, 6), 256),
+                             ("lattice 1000", _cloud(2, 1000, 7, grid=True), 100), ("lattice 4096 x 0.1", _cloud(1, 4096, 8, grid=True) * np.float32(0.4), 256)):
+            fps, bq, nn, d2 = {}, {}, {}, {}
+            new = xyz[:, ::7].copy()
+            for mode in modes:
+                po.set_contraction(mode)
+                fps[mode] = po.furthest_point_sampling(xyz, m)
+                bq[mode] = po.ball_query(0.6, 16, xyz, new)
+                d2[mode], nn[mode] = po.three_nn(new + np.float32(0.013), xyz)
+            for a, b in (("fma_llvm", "fma_chain"), ("fma_llvm", "none"), ("fma_chain", "none")):
+                report.append((name, a, b, int((fps[a] != fps[b]).sum()), fps[a].size, int((bq[a] != bq[b]).sum()), bq[a].size,
+                               int((nn[a] != nn[b]).sum()), nn[a].size))
+                ulp = np.abs(d2[a].view(np.int32).astype(np.int64) - d2[b].view(np.int32).astype(np.int64))
+                assert ulp[nn[a] == nn[b]].max() <= 2
+            if name.startswith("random"):
+                assert np.array_equal(fps["fma_llvm"], fps["fma_chain"]) and np.array_equal(fps["fma_llvm"], fps["none"])
+        # a constructed flip: two candidates whose squared distances from point 0 differ only in how the sum is rounded
+        rng = np.random.RandomState(11)
+        flips = 0
+        for _ in range(4000):
+            v = rng.randn(3).astype(np.float32)
+            picks = set()
+            for mode in modes:
+                po.set_contraction(mode)
+                dd = po.three_nn(np.zeros((1, 1, 3), np.float32), np.stack([v, v[[1, 0, 2]], v[[2, 1, 0]]])[None])[0]
+                picks.add(dd.tobytes())
+            flips += len(picks) > 1
+        assert flips > 0          # permuting the coordinates changes the rounded sum in some mode: the modes are not the same function
+    finally:
+        po.set_contraction("fma_llvm")
+    with capsys.disabled():
+        print("\n[pointops contraction] index entries that differ between modes (FPS | ball query | 3-NN):")
+        for name, a, b, f, fn, q, qn, t, tn in report:
+            print(f"[pointops contraction]   {name:20s} {a:9s} vs {b:9s}: {f}/{fn} | {q}/{qn} | {t}/{tn}")

@@ -17,10 +17,24 @@
 
 namespace {
 
-__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz) {
-  const float dx = bx - ax, dy = by - ay, dz = bz - az;
-  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+// `a*a + b*b + c*c` and `w0*p0 + w1*p1 + w2*p2` as the reference's kernels write them (sampling_gpu.cu:140, ball_query_gpu.cu:38,
+// interpolate_gpu.cu:40, :103) are compiled by nvcc with -fmad=true: WHICH product is rounded on its own before the two fused
+// multiply-adds decides ties, and FPS is a chaotic integer selection -- so the contraction is a call-time mode
+// (u3d_pointops_set_contraction), bit-exact against oracle/pointops_oracle.c in every mode:
+//   U3D_PO_FMA_LLVM (default)  fma(c, c, fma(a, a, b*b))  what LLVM's DAG combiner -- NVVM is LLVM -- makes of fadd(fadd(fmul, fmul), fmul):
+//                              the FIRST operand's multiply is folded into the inner add, the second product stays a rounded fmul
+//   U3D_PO_FMA_CHAIN           fma(c, c, fma(b, b, a*a))  rounds 1-3's reading (left-to-right chain, first product rounded)
+//   U3D_PO_NO_FMA              ((a*a + b*b) + c*c) with every product rounded: -fmad=false
+__device__ __forceinline__ float sum3(float a0, float a1, float b0, float b1, float c0, float c1, int cm) {   // a0*a1 + b0*b1 + c0*c1
+  if (cm == U3D_PO_FMA_LLVM) return fmaf(c0, c1, fmaf(a0, a1, __fmul_rn(b0, b1)));
+  if (cm == U3D_PO_FMA_CHAIN) return fmaf(c0, c1, fmaf(b0, b1, __fmul_rn(a0, a1)));
+  return __fadd_rn(__fadd_rn(__fmul_rn(a0, a1), __fmul_rn(b0, b1)), __fmul_rn(c0, c1));
 }
+__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz, int cm) {
+  const float dx = bx - ax, dy = by - ay, dz = bz - az;
+  return sum3(dx, dx, dy, dy, dz, dz, cm);
+}
+int g_contraction = U3D_PO_FMA_LLVM;   // host: mode of the launches that follow (process-wide, like a build flag of the reference)
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
 #pragma unroll
@@ -69,7 +83,7 @@ __device__ __forceinline__ int fps_decode(uint32_t tk, int lg) {
 }
 
 template <int FPS_THREADS, int PPT>
-__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int lg, const float* __restrict__ dataset,
+__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int lg, int cm, const float* __restrict__ dataset,
                                                           int32_t* __restrict__ idxs) {
   constexpr int FPS_WAVES = FPS_THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) float s_xyz[];   // [n][3]
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int lg, 
     uint32_t bt = 0u;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      const float d = dist2(ox, oy, oz, x[i], y[i], z[i]);
+      const float d = dist2(ox, oy, oz, x[i], y[i], z[i], cm);
       t[i] = fminf(d, t[i]);
       const bool take = t[i] > bd || (t[i] == bd && inv_tk[i] > bt);
       bd = take ? t[i] : bd;
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int lg, 
 }
 
 // generic path for clouds larger than FPS_THREADS*8 points: minimum distances in global scratch
-__global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int lg, const float* __restrict__ dataset,
+__global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int lg, int cm, const float* __restrict__ dataset,
                                                          float* __restrict__ temp, int32_t* __restrict__ idxs) {
   constexpr int FPS_THREADS = 1024, FPS_WAVES = 16;
   __shared__ unsigned long long s_key[2][FPS_WAVES];
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int lg, c
     const float ox = ds[old * 3], oy = ds[old * 3 + 1], oz = ds[old * 3 + 2];
     unsigned long long best = 0ull;
     for (int k = tid; k < n; k += FPS_THREADS) {
-      const float d = dist2(ox, oy, oz, ds[k * 3], ds[k * 3 + 1], ds[k * 3 + 2]);
+      const float d = dist2(ox, oy, oz, ds[k * 3], ds[k * 3 + 1], ds[k * 3 + 2], cm);
       const float d2 = fminf(d, tp[k]);
       tp[k] = d2;
       const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (0xFFFFFFFFu - fps_tie_key((uint32_t)k, lg, bs));
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int lg, c
   }
 }
 
-__global__ __launch_bounds__(256) void ball_query_kernel(int n, int m, int total_q, float radius2, int nsample,
+__global__ __launch_bounds__(256) void ball_query_kernel(int n, int m, int total_q, float radius2, int nsample, int cm,
                                                          const float* __restrict__ new_xyz, const float* __restrict__ xyz,
                                                          int32_t* __restrict__ idx) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -172,7 +186,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(int n, int m, int total
     bool in = false;
     if (k < n) {
       const float dx = qx - pts[k * 3], dy = qy - pts[k * 3 + 1], dz = qz - pts[k * 3 + 2];
-      in = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < radius2;
+      in = sum3(dx, dx, dy, dy, dz, dz, cm) < radius2;
     }
     const unsigned long long bal = __ballot(in);
     if (bal) {
@@ -213,7 +227,7 @@ __global__ void group_points_grad_kernel(int c, int n, int npoints, int nsample,
 // the lower index -- reproduced exactly; an unfilled slot keeps the reference's initial 1e40 (stored as +inf) / index 0.
 constexpr int NN_THREADS = 128;
 constexpr int NN_TILE = 2048;   // known points per LDS tile: 24 KB
-__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(int n, int m, const float* __restrict__ unknown,
+__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(int n, int m, int cm, const float* __restrict__ unknown,
                                                               const float* __restrict__ known, float* __restrict__ dist2,
                                                               int32_t* __restrict__ idx) {
   __shared__ float s_k[NN_TILE * 3];
@@ -232,7 +246,7 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(int n, int m, cons
     __syncthreads();
     for (int j = 0; j < cnt; ++j) {
       const float dx = ux - s_k[j * 3], dy = uy - s_k[j * 3 + 1], dz = uz - s_k[j * 3 + 2];
-      const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));   // (ux-x)^2 + (uy-y)^2 + (uz-z)^2 as nvcc contracts it
+      const float d = sum3(dx, dx, dy, dy, dz, dz, cm);   // (ux-x)^2 + (uy-y)^2 + (uz-z)^2 in the selected contraction
       const int k = k0 + j;
       if (d < best1) { best3 = best2; i3 = i2; best2 = best1; i2 = i1; best1 = d; i1 = k; }
       else if (d < best2) { best3 = best2; i3 = i2; best2 = d; i2 = k; }
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(int n, int m, cons
 // row of m values (cache-resident) and one coalesced store per channel.  out = w0 p[i0] + w1 p[i1] + w2 p[i2], contracted
 // left to right like nvcc does (fma(w2, p2, fma(w1, p1, w0 p0))).
 constexpr int IC_CH = 8;
-__global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, int n, const float* __restrict__ points,
+__global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, int n, int cm, const float* __restrict__ points,
                                                                 const int32_t* __restrict__ idx, const float* __restrict__ weight,
                                                                 float* __restrict__ out) {
   const int bi = blockIdx.z, c0 = blockIdx.y * IC_CH;
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, in
   const int c1 = min(c, c0 + IC_CH);
   for (int ci = c0; ci < c1; ++ci) {
     const float* row = points + ((size_t)bi * c + ci) * m;
-    out[((size_t)bi * c + ci) * n + pt] = fmaf(w2, row[i2], fmaf(w1, row[i1], w0 * row[i0]));
+    out[((size_t)bi * c + ci) * n + pt] = sum3(w0, row[i0], w1, row[i1], w2, row[i2], cm);
   }
 }
 
@@ -305,7 +319,7 @@ int u3d_furthest_point_sampling(int b, int n, int m, const float* points, float*
   }
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)n * 3 * sizeof(float);
-#define FPS(T, P) hipLaunchKernelGGL((fps_kernel<T, P>), dim3(b), dim3(T), lds, s, n, m, lg, points, idx)
+#define FPS(T, P) hipLaunchKernelGGL((fps_kernel<T, P>), dim3(b), dim3(T), lds, s, n, m, lg, g_contraction, points, idx)
   // small clouds: 4 waves keep the per-sample dependency chain short; larger ones spread over 16 waves
   if (n <= 256) FPS(256, 1);
   else if (n <= 512) FPS(256, 2);
@@ -315,7 +329,7 @@ int u3d_furthest_point_sampling(int b, int n, int m, const float* points, float*
   else if (n <= 8192) FPS(1024, 8);
   else {
     if (!temp) return 1;
-    hipLaunchKernelGGL(fps_kernel_large, dim3(b), dim3(1024), 0, s, n, m, lg, points, temp, idx);
+    hipLaunchKernelGGL(fps_kernel_large, dim3(b), dim3(1024), 0, s, n, m, lg, g_contraction, points, temp, idx);
   }
 #undef FPS
   return hipGetLastError() == hipSuccess ? 0 : 3;
@@ -328,7 +342,7 @@ int u3d_ball_query(int b, int n, int m, float radius, int nsample, const float* 
   if (!new_xyz || !xyz || !idx) return 1;
   const int total = b * m;
   hipLaunchKernelGGL(ball_query_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, n, m, total, radius * radius,
-                     nsample, new_xyz, xyz, idx);
+                     nsample, g_contraction, new_xyz, xyz, idx);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -367,7 +381,7 @@ int u3d_three_nn(int b, int n, int m, const float* unknown, const float* known, 
   if (b == 0 || n == 0) return 0;
   if (b > 65535) return 1;
   if (!unknown || (m > 0 && !known) || !dist2 || !idx) return 1;
-  hipLaunchKernelGGL(three_nn_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS, b), dim3(NN_THREADS), 0, (hipStream_t)stream, n, m, unknown,
+  hipLaunchKernelGGL(three_nn_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS, b), dim3(NN_THREADS), 0, (hipStream_t)stream, n, m, g_contraction, unknown,
                      known, dist2, idx);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
@@ -379,7 +393,7 @@ int u3d_three_interpolate(int b, int c, int m, int n, const float* points, const
   if (b > 65535 || (c + IC_CH - 1) / IC_CH > 65535) return 1;
   if (!points || !idx || !weight || !out) return 1;
   hipLaunchKernelGGL(three_interpolate_kernel, dim3((n + 255) / 256, (c + IC_CH - 1) / IC_CH, b), dim3(256), 0, (hipStream_t)stream, c, m,
-                     n, points, idx, weight, out);
+                     n, g_contraction, points, idx, weight, out);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -393,5 +407,12 @@ int u3d_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out
                      c, n, m, grad_out, idx, weight, grad_points);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
+
+int u3d_pointops_set_contraction(int mode) {
+  if (mode != U3D_PO_FMA_LLVM && mode != U3D_PO_FMA_CHAIN && mode != U3D_PO_NO_FMA) return 1;
+  g_contraction = mode;
+  return 0;
+}
+int u3d_pointops_get_contraction(void) { return g_contraction; }
 
 }  // extern "C"

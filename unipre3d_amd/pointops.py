@@ -16,7 +16,18 @@ from . import _lib
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunipre3d_pointops.so")
 EXPORTS = ("u3d_furthest_point_sampling", "u3d_ball_query", "u3d_group_points", "u3d_group_points_grad",
-           "u3d_gather_points", "u3d_gather_points_grad", "u3d_three_nn", "u3d_three_interpolate", "u3d_three_interpolate_grad")
+           "u3d_gather_points", "u3d_gather_points_grad", "u3d_three_nn", "u3d_three_interpolate", "u3d_three_interpolate_grad",
+           "u3d_pointops_set_contraction", "u3d_pointops_get_contraction")
+CONTRACTIONS = {"fma_llvm": 0, "fma_chain": 1, "none": 2}    # include/unipre3d_pointops.h: U3D_PO_*
+
+
+def set_contraction(mode: str) -> None:
+    """How the reference's three-term sums (squared distances, interpolation) are contracted -- what nvcc's -fmad=true would have
+    chosen decides FPS ties.  'fma_llvm' (default: LLVM's combiner order, NVVM is LLVM), 'fma_chain' (rounds 1-3 of this build),
+    'none' (-fmad=false).  Process-wide, applies to the launches that follow."""
+    rc = load().u3d_pointops_set_contraction(CONTRACTIONS[mode])
+    if rc != 0:
+        raise ValueError(f"unknown contraction mode {mode!r}")
 _po = None
 
 
@@ -36,6 +47,8 @@ def load() -> ctypes.CDLL:
         lib.u3d_three_nn.argtypes = [i, i, i, vp, vp, vp, vp, vp]
         lib.u3d_three_interpolate.argtypes = [i, i, i, i, vp, vp, vp, vp, vp]
         lib.u3d_three_interpolate_grad.argtypes = [i, i, i, i, vp, vp, vp, vp, vp]
+        lib.u3d_pointops_set_contraction.argtypes = [i]
+        lib.u3d_pointops_get_contraction.argtypes = []
         for n in EXPORTS:
             getattr(lib, n).restype = ctypes.c_int
         _po = lib
