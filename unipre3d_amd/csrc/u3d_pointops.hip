@@ -26,9 +26,10 @@ namespace {
 //   U3D_PO_FMA_CHAIN           fma(c, c, fma(b, b, a*a))  rounds 1-3's reading (left-to-right chain, first product rounded)
 //   U3D_PO_NO_FMA              ((a*a + b*b) + c*c) with every product rounded: -fmad=false
 __device__ __forceinline__ float sum3(float a0, float a1, float b0, float b1, float c0, float c1, int cm) {   // a0*a1 + b0*b1 + c0*c1
-  if (cm == U3D_PO_FMA_LLVM) return fmaf(c0, c1, fmaf(a0, a1, __fmul_rn(b0, b1)));
-  if (cm == U3D_PO_FMA_CHAIN) return fmaf(c0, c1, fmaf(b0, b1, __fmul_rn(a0, a1)));
-  return __fadd_rn(__fadd_rn(__fmul_rn(a0, a1), __fmul_rn(b0, b1)), __fmul_rn(c0, c1));
+#pragma clang fp contract(off)   // (only the fmaf calls below fuse; HIP's __fmul_rn / __fadd_rn are plain operators the optimiser may contract)
+  if (cm == U3D_PO_FMA_LLVM) return fmaf(c0, c1, fmaf(a0, a1, b0 * b1));
+  if (cm == U3D_PO_FMA_CHAIN) return fmaf(c0, c1, fmaf(b0, b1, a0 * a1));
+  return (a0 * a1 + b0 * b1) + c0 * c1;
 }
 __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz, int cm) {
   const float dx = bx - ax, dy = by - ay, dz = bz - az;
