@@ -84,7 +84,7 @@ U3DSource head_source(const u3d_raster_desc& d, const u3d_head_desc& h, const fl
   src.center = center;
   src.offset_scale = h.offset_scale;
   src.qnorm = qnorm;
-  src.qnorm_out = nullptr; src.qdot_zero = nullptr; src.qcount_zero = nullptr;
+  src.qnorm_out = nullptr; src.qdot_zero = nullptr;
   (void)d;
   return src;
 }
@@ -423,7 +423,7 @@ int u3d_render_loss_backward(const u3d_raster_desc* desc, const u3d_head_desc* h
   double* acc = (double*)backward_scratch;
   float* part = (float*)((char*)backward_scratch + Lay.acc_bytes);
   (void)hipMemsetAsync(acc, 0, Lay.acc_bytes, s);
-  (void)hipMemsetAsync(f.qdot, 0, (size_t)((char*)f.partial - (char*)f.qdot), s);   // qdot and the arrival counters behind it
+  (void)hipMemsetAsync(f.qdot, 0, sizeof(float) * 4 * d.n_items, s);
   const U3DLoss L = make_loss(d, *loss, gt, f.partial, dloss);
   {
     ProfScope ps(3, s);
@@ -432,13 +432,13 @@ int u3d_render_loss_backward(const u3d_raster_desc* desc, const u3d_head_desc* h
   const int C = head->channels;
   U3DGradSink sink{};
   sink.means = d_head_out; sink.opac = d_head_out + 3; sink.scales = d_head_out + 4; sink.rots = d_head_out + 7;
-  sink.shs = d_head_out + 11; sink.colors = nullptr; sink.cov = nullptr; sink.means2D = nullptr; sink.qdot = f.qdot; sink.qcount = f.qcount;
+  sink.shs = d_head_out + 11; sink.colors = nullptr; sink.cov = nullptr; sink.means2D = nullptr; sink.qdot = f.qdot;
   {
     ProfScope ps(4, s);
     u3d_launch_preprocess_bwd(d, b, head_source(d, *head, head_out, center, f.qnorm), viewmatrix, projmatrix, campos, radii,
                               acc, sink, s);
   }
-  (void)C;   // (object level: the last workgroup of every set finishes the across-point normalise backward inside preprocess_bwd)
+  if (head->mode == 1) u3d_launch_quat_fixup(d, head_out + 7, C, f.qnorm, f.qdot, d_head_out + 7, s);
   return finish(desc, s);
 }
 
@@ -469,8 +469,8 @@ int u3d_render_loss_step_forward(const u3d_raster_desc* desc, const u3d_head_des
   // no memset nodes: quat_norms clears qdot, preprocess_fwd clears the accumulators of the (view, Gaussian) it projects
   U3DSource src = head_source(d, *head, head_out, center, f.qnorm);
   if (head->mode == 1) {
-    if (u3d_preprocess_sorts(d)) { src.qnorm_out = f.qnorm; src.qdot_zero = f.qdot; src.qcount_zero = f.qcount; }   // P <= 256: inside preprocess_fwd
-    else u3d_launch_quat_norms(d, head_out + 7, head->channels, f.qnorm, f.qdot, s, f.qcount);
+    if (u3d_preprocess_sorts(d)) { src.qnorm_out = f.qnorm; src.qdot_zero = f.qdot; }   // P <= 256: inside preprocess_fwd
+    else u3d_launch_quat_norms(d, head_out + 7, head->channels, f.qnorm, f.qdot, s);
   }
   {
     ProfScope ps(0, s);
@@ -515,12 +515,13 @@ int u3d_render_loss_step_backward(const u3d_raster_desc* desc, const u3d_head_de
   const U3DSource src = head_source(d, *head, head_out, center, f.qnorm);
   U3DGradSink sink{};
   sink.means = d_head_out; sink.opac = d_head_out + 3; sink.scales = d_head_out + 4; sink.rots = d_head_out + 7;
-  sink.shs = d_head_out + 11; sink.colors = nullptr; sink.cov = nullptr; sink.means2D = nullptr; sink.qdot = f.qdot; sink.qcount = f.qcount;
+  sink.shs = d_head_out + 11; sink.colors = nullptr; sink.cov = nullptr; sink.means2D = nullptr; sink.qdot = f.qdot;
   {
     ProfScope ps(4, s);
     u3d_launch_preprocess_bwd(d, b, src, viewmatrix, projmatrix, campos, radii, acc, sink, s, acc, dloss,
                               u3d_sparse_bwd(d, head->mode));   // reads, then re-zeroes, the touched accumulators
   }
+  if (head->mode == 1) u3d_launch_quat_fixup(d, head_out + 7, head->channels, f.qnorm, f.qdot, d_head_out + 7, s);
   return finish(desc, s);
 }
 

@@ -136,7 +136,6 @@ struct U3DSource {
   // here for the backward, and clears qdot_zero -- no separate quat_norms launch
   float* qnorm_out;
   float* qdot_zero;
-  uint32_t* qcount_zero;   // [B] arrival counters of the backward's per-set finish (cleared wherever qdot is)
 };
 
 // Where per-Gaussian gradients go (same strides as the source; act != 0 chains through the activations).
@@ -144,9 +143,7 @@ struct U3DGradSink {
   float* means; float* shs; float* colors; float* opac; float* scales; float* rots; float* cov;
   float* shs_rest;      // split SH: gradient of coefficients 1.. (same layout as U3DSource::shs_rest), else null
   float* means2D;       // [NV][P][3] or null
-  float* qdot;          // [B][4] sum_i raw_rot[i][c] * g[i][c]  (act == 1): summed by the workgroups of a set; the LAST of them to
-                        // arrive (qcount) applies the second term of the across-point normalise backward to the set's rows
-  uint32_t* qcount;     // [B]
+  float* qdot;          // [B][4] sum_i raw_rot[i][c] * g[i][c]  (act == 1; finished by u3d_quat_fixup)
 };
 
 // Optional fused render loss: utils/loss_utils.py:17-45 evaluated in the render epilogue /
@@ -164,9 +161,9 @@ struct U3DLayout {
   size_t geom_bytes, binning_bytes, image_bytes, backward_bytes, acc_bytes, num_rendered_offset, fused_bytes;
 };
 
-// fused scratch: [qnorm n_items*4][qdot n_items*4][qcount n_items][loss partial NV*T]
+// fused scratch: [qnorm n_items*4][qdot n_items*4][loss partial NV*T]
 struct U3DFused {
-  float* qnorm; float* qdot; uint32_t* qcount; float* partial;
+  float* qnorm; float* qdot; float* partial;
 };
 static inline size_t u3d_carve_fused(const u3d_raster_desc& d, void* base, U3DFused* f) {
   const size_t NV = (size_t)d.n_items * d.views_per_item;
@@ -175,10 +172,9 @@ static inline size_t u3d_carve_fused(const u3d_raster_desc& d, void* base, U3DFu
   if (f) {
     f->qnorm = (float*)base;
     f->qdot = (float*)((char*)base + a);
-    f->qcount = (uint32_t*)((char*)base + 2 * a);
-    f->partial = (float*)((char*)base + 3 * a);
+    f->partial = (float*)((char*)base + 2 * a);
   }
-  return 3 * a + (((NV * T * sizeof(float)) + 255) & ~(size_t)255) + 256;
+  return 2 * a + (((NV * T * sizeof(float)) + 255) & ~(size_t)255) + 256;
 }
 
 // partial-row buffer: U3D_PART_BLOCKS blocks of 64 sorted positions x 10 floats per tile (positions beyond go through f64
@@ -270,8 +266,9 @@ static inline bool u3d_sparse_bwd(const u3d_raster_desc& d, int head_mode) {
 }
 // true when preprocess_fwd also produces the per-view depth order (P <= 256): skip u3d_launch_depth_sort then
 bool u3d_preprocess_sorts(const u3d_raster_desc& d);
-void u3d_launch_quat_norms(const u3d_raster_desc& d, const float* rots, int s_rots, float* qnorm, float* qdot_zero, hipStream_t s,
-                           uint32_t* qcount_zero = nullptr);
+void u3d_launch_quat_norms(const u3d_raster_desc& d, const float* rots, int s_rots, float* qnorm, float* qdot_zero, hipStream_t s);
+void u3d_launch_quat_fixup(const u3d_raster_desc& d, const float* rots, int s_rots, const float* qnorm, const float* qdot,
+                           float* d_rots, hipStream_t s);
 void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const int32_t* radii, hipStream_t s);
 void u3d_launch_render_fwd(const u3d_raster_desc& d, const U3DBuffers& b, const float* bg, float* out_color,
                            float* out_invdepth, const U3DLoss& loss, hipStream_t s);

@@ -191,7 +191,6 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
         if (blockIdx.z == 0) {
           src.qnorm_out[item * 4 + threadIdx.x] = n;
           if (src.qdot_zero) src.qdot_zero[item * 4 + threadIdx.x] = 0.f;
-          if (src.qcount_zero && threadIdx.x == 0) src.qcount_zero[item] = 0u;
         }
       }
       __syncthreads();
@@ -350,7 +349,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     const uint2* __restrict__ sparse_list, const uint32_t* __restrict__ sparse_count) {
 #pragma clang fp contract(fast)
   // gscale: device scalar dL/dloss of the fused step (autograd's grad_output) or null (= 1).  Every output of this kernel -- and the
-  // column dot products the set's last workgroup finishes -- is linear in the accumulators, so scaling them as they are read IS the d_head * g
+  // column dot products quat_fixup finishes -- is linear in the accumulators, so scaling them as they are read IS the d_head * g
   // multiply; a wave-uniform scalar load, no extra launch.
   const float gs = gscale ? gscale[0] : 1.f;
   // 4 consecutive lanes (a DPP quad) share one Gaussian and split its views: lane&3 = view slot
@@ -701,7 +700,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
         for (int k = 0; k < 4; ++k) drot[k] = n > 1e-6f ? drot[k] / n - gin.raw_q[k] * dot / (n2 * n) : drot[k] / 1e-6f;
       } else {
         // across-point normalise (object level): first term here, the column dot product is reduced below and the
-        // second term is applied by the set's last-arriving workgroup, at the end of this kernel
+        // second term is applied by quat_fixup_kernel
 #pragma unroll
         for (int k = 0; k < 4; ++k) { qd[k] = drot[k] * gin.raw_q[k]; drot[k] = drot[k] / gin.qn[k]; }
       }
@@ -748,40 +747,13 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
       const float v = s_qdot[0][threadIdx.x] + s_qdot[1][threadIdx.x] + s_qdot[2][threadIdx.x] + s_qdot[3][threadIdx.x];
       unsafeAtomicAdd(&sink.qdot[item * 4 + threadIdx.x], v);
     }
-    // The second term of the across-point normalise backward, d x_i -= x_i (sum_j x_j g_j) / n^3, needs the set's complete column
-    // sums: the workgroups of a set count their arrivals, and the LAST one applies it to all of the set's rows (written by the others:
-    // release by fence + counter, reads past the L1) -- formerly a launch of its own (quat_fixup, 4.8 us of a 213 us C2 step).
-    __shared__ uint32_t s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&sink.qcount[item], 1u) == gridDim.x - 1u ? 1u : 0u;
-    __syncthreads();
-    if (s_last) {
-      __threadfence();
-      float qd4[4], n4[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        qd4[k] = __hip_atomic_load(&sink.qdot[item * 4 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        n4[k] = src.qnorm[item * 4 + k];
-      }
-      for (int e = threadIdx.x; e < P * 4; e += U3D_BLOCK) {
-        const int r = e >> 2, k = e & 3;
-        const size_t o = (gbase + r) * (size_t)src.s_rots + k;
-        const float n = n4[k];
-        if (n > 1e-6f) {
-          const float g0 = __hip_atomic_load(&sink.rots[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          sink.rots[o] = g0 - src.rots[o] * qd4[k] / (n * n * n);
-        }
-      }
-    }
   }
 }
 
 // across-point quaternion norms: qnorm[item][c] = || raw_rot[item, :, c] ||_2   (F.normalize(x(B,4,N), dim=-1))
 constexpr int QN_THREADS = 1024;   // one workgroup per set: 16 waves keep more of the strided loads in flight (7.5 -> ~4 us at P = 2048)
 __global__ __launch_bounds__(QN_THREADS) void quat_norms_kernel(U3DSpan span, const float* __restrict__ rots, int s_rots,
-                                                                float* __restrict__ qnorm, float* __restrict__ qdot_zero,
-                                                                uint32_t* __restrict__ qcount_zero) {
+                                                                float* __restrict__ qnorm, float* __restrict__ qdot_zero) {
   __shared__ float sm[QN_THREADS / 64][4];
   const int item = blockIdx.x;
   int P;
@@ -806,7 +778,24 @@ __global__ __launch_bounds__(QN_THREADS) void quat_norms_kernel(U3DSpan span, co
     for (int w = 0; w < QN_THREADS / 64; ++w) t += sm[w][threadIdx.x];
     qnorm[item * 4 + threadIdx.x] = sqrtf(t);
     if (qdot_zero) qdot_zero[item * 4 + threadIdx.x] = 0.f;
-    if (qcount_zero && threadIdx.x == 0) qcount_zero[item] = 0u;
+  }
+}
+
+// second term of the across-point normalise backward: d x_i -= x_i * (sum_j x_j g_j) / n^3  when n > eps
+__global__ __launch_bounds__(U3D_BLOCK) void quat_fixup_kernel(U3DSpan span, const float* __restrict__ rots, int s_rots,
+                                                               const float* __restrict__ qnorm, const float* __restrict__ qdot,
+                                                               float* __restrict__ d_rots) {
+  const int item = blockIdx.y;
+  int P;
+  size_t gbase;
+  u3d_set_span(span, item, P, gbase);
+  const int i = blockIdx.x * U3D_BLOCK + threadIdx.x;
+  if (i >= P) return;
+  const size_t o = (gbase + i) * s_rots;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float n = qnorm[item * 4 + k];
+    if (n > 1e-6f) d_rots[o + k] -= rots[o + k] * qdot[item * 4 + k] / (n * n * n);
   }
 }
 
@@ -877,9 +866,14 @@ void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, co
 #undef LAUNCH
 }
 
-void u3d_launch_quat_norms(const u3d_raster_desc& d, const float* rots, int s_rots, float* qnorm, float* qdot_zero, hipStream_t s,
-                           uint32_t* qcount_zero) {
-  hipLaunchKernelGGL(quat_norms_kernel, dim3(d.n_items), dim3(QN_THREADS), 0, s, u3d_span(d), rots, s_rots, qnorm, qdot_zero, qcount_zero);
+void u3d_launch_quat_norms(const u3d_raster_desc& d, const float* rots, int s_rots, float* qnorm, float* qdot_zero, hipStream_t s) {
+  hipLaunchKernelGGL(quat_norms_kernel, dim3(d.n_items), dim3(QN_THREADS), 0, s, u3d_span(d), rots, s_rots, qnorm, qdot_zero);
+}
+
+void u3d_launch_quat_fixup(const u3d_raster_desc& d, const float* rots, int s_rots, const float* qnorm, const float* qdot,
+                           float* d_rots, hipStream_t s) {
+  hipLaunchKernelGGL(quat_fixup_kernel, dim3((d.P + U3D_BLOCK - 1) / U3D_BLOCK, d.n_items), dim3(U3D_BLOCK), 0, s, u3d_span(d), rots,
+                     s_rots, qnorm, qdot, d_rots);
 }
 
 void u3d_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s) {

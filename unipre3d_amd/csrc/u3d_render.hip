@@ -293,15 +293,6 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
   typedef __attribute__((address_space(3))) float lds_float;
   const uint32_t acc_lane = (uint32_t)(uintptr_t)(lds_float*)&L.acc[0][0] + 4u * (uint32_t)bank;
   const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
-#ifdef U3D_BWD_LIM_EARLYOUT
-  uint32_t minlim;
-  {
-    uint32_t ml = min(min(lim[0], lim[1]), min(lim[2], lim[3]));   // (a pixel outside the image has limit 0: edge tiles never qualify)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ml = min(ml, (uint32_t)__shfl_xor((int)ml, o));
-    minlim = __builtin_amdgcn_readfirstlane(ml);
-  }
-#endif
   for (int b = nb - 1; b >= 0; --b) {
     lanemask_t bal = staged_bal;
     if (b != staged) { bool plain; bal = tile_stage<HAS_INVD>(L, G, lane, b, wmax, plain); staged = b; staged_bal = bal; }
@@ -318,22 +309,6 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
       const float bdy = A.w * dy, cdy2 = (Q.x * dy) * dy;
       float dx[4], ae[4];
       lanemask_t any = 0ull;
-#ifdef U3D_BWD_LIM_EARLYOUT
-      // (experiment, round 4: entries in front of the tile's FIRST saturating pixel need no per-pixel limit test -- one scalar compare
-      // selects a copy of the block without the four v_cmp_lt_u32 and their s_and)
-      if (__builtin_amdgcn_readfirstlane(pos) < minlim) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          dx[k] = A.x - pxf[k];
-          const float pw = fmaf(fmaf(A.z, dx[k], bdy), dx[k], cdy2);
-          const float araw = Q.y * __builtin_amdgcn_exp2f(pw);
-          const lanemask_t m_a = (PLAIN ? ~0ull : __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE)) & __builtin_amdgcn_fcmpf(araw, ALPHA_MIN, U3D_FCMP_OGE);
-          any |= m_a;
-          ae[k] = mask_sel0(m_a, araw);
-        }
-      } else
-#endif
-      {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         dx[k] = A.x - pxf[k];
@@ -341,7 +316,6 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
         const float araw = Q.y * __builtin_amdgcn_exp2f(pw);   // opacity * G (alpha before the 0.99 clamp)
         const lanemask_t m_a = (PLAIN ? ~0ull : __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE)) & __builtin_amdgcn_fcmpf(araw, ALPHA_MIN, U3D_FCMP_OGE);
         ae[k] = mask_combine_sel0<false>(m_a, __builtin_amdgcn_uicmp(pos, lim[k], U3D_ICMP_ULT), any, araw);
-      }
       }
       if (any == 0ull) continue;
       float m0, mx, mxx, g_r, g_g, g_b, g_d = 0.f;
