@@ -42,7 +42,7 @@ print(json.dumps({
 PY
 if [ "$CFG" = "C2" ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/pmcf_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcf_$c -- python $R/bench.py --config C2 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-other-configs > $O/pmcf_${c}.log 2>&1
+    rm -rf /tmp/pmcf_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcf_$c -- python $R/bench.py --config C2 --steps 5 --warmup 2 --no-cpu-baseline --hot-only > $O/pmcf_${c}.log 2>&1
     cp $(find /tmp/pmcf_$c -name "*counter_collection.csv" | head -1) /tmp/ccf_$c.csv
   done
   python - <<'PY' > $O/pmc_traffic_fwd_C2.json
@@ -58,7 +58,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         per[k][c + "_KB"] = acc[k] / n[k]; per[k]["launches_" + c] = n[k]
 for k, v in per.items():
     v["hbm_bytes_corrected"] = (2 * v.get("FETCH_SIZE_KB", 0.0) + v.get("WRITE_SIZE_KB", 0.0)) * 1024
-print(json.dumps({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --config C2 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-other-configs (two passes); rows of the forward-only tile kernel (bench region forward_rasterizer; <true> = with the inverse-depth plane)",
+print(json.dumps({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --config C2 --steps 5 --warmup 2 --no-cpu-baseline --hot-only (two passes); rows of the forward-only tile kernel over the 128 views of the batch (bench region forward_rasterizer; <true> = with the inverse-depth plane, <false> = u3d_render_view_forward)",
                   "formula": "hbm_bytes_corrected = (2*FETCH_SIZE_KB + WRITE_SIZE_KB) * 1024", "per_launch": per}, indent=1))
 PY
 fi
