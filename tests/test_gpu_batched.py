@@ -768,6 +768,43 @@ def test_render_predicted_one_call_body_equals_the_op_by_op_body(oracle_mod, deg
     assert s1 is not a["viewspace_points"] and s1.grad is None and a["viewspace_points"].grad is not None
 
 
+def test_render_predicted_one_call_body_edge_cases():
+    """The one-call body under the conditions the reference's callers produce: torch.no_grad() (eval.py:101-109), float64 / non-contiguous
+    inputs (converted like the operator does), no Gaussians at all (background image), an override colour or per-view focals (general body)."""
+    import types
+    from unipre3d_amd import renderer
+    from scenes import scene
+    dev = torch.device("cuda:0")
+    H, W, P = 48, 64, 70
+    sc = scene(P, H, W, seed=3, level="object", compact=False, deg=1)
+    cfg = types.SimpleNamespace(data=types.SimpleNamespace(fov=2 * math.degrees(math.atan(sc["tanfovx"])), training_height=H, training_width=W),
+                                model=types.SimpleNamespace(max_sh_degree=1))
+    cams = (sc["viewmatrix"].to(dev), sc["projmatrix"].to(dev), sc["campos"].to(dev), sc["bg"].to(dev))
+    pc = {"xyz": sc["means3D"], "opacity": sc["opacities"], "scaling": sc["scales"], "rotation": sc["rotations"],
+          "features_dc": sc["shs"][:, :1].contiguous(), "features_rest": sc["shs"][:, 1:].contiguous()}
+    pc = {k: v.to(dev) for k, v in pc.items()}
+    ref = renderer.render_predicted(pc, *cams, cfg)
+    with torch.no_grad():
+        out = renderer.render_predicted(pc, *cams, cfg)
+    assert torch.equal(out["render"], ref["render"]) and not out["render"].requires_grad
+    odd = {k: v.double() for k, v in pc.items()}
+    odd["xyz"] = torch.cat([odd["xyz"], odd["xyz"]], dim=1)[:, :3]                      # a non-contiguous view
+    assert not odd["xyz"].is_contiguous()
+    out = renderer.render_predicted(odd, *cams, cfg)
+    assert out["render"].dtype == torch.float32 and torch.equal(out["render"], ref["render"]) and torch.equal(out["radii"], ref["radii"])
+    empty = {k: v[:0] for k, v in pc.items()}
+    out = renderer.render_predicted(empty, *cams, cfg)
+    assert out["radii"].numel() == 0 and out["visibility_filter"].numel() == 0
+    assert torch.equal(out["render"], sc["bg"].to(dev)[:, None, None].expand(3, H, W))
+    col = torch.rand(P, 3, device=dev)
+    a = renderer.render_predicted(pc, *cams, cfg, override_color=col)                  # general body: precomputed colours
+    assert a["render"].shape == (3, H, W) and not torch.equal(a["render"], ref["render"])
+    sq = types.SimpleNamespace(data=types.SimpleNamespace(fov=cfg.data.fov, training_resolution=H), model=cfg.model)
+    f = torch.tensor([H / (2 * sc["tanfovx"])] * 2)
+    b = renderer.render_predicted(pc, *cams, sq, focals_pixels=f)                       # general body: per-view focal lengths
+    assert b["render"].shape == (3, H, H) and b["viewspace_points"].shape == (P, 3)
+
+
 class _DropGrad(torch.autograd.Function):
     """y = x; hands NO gradient back (None): the node upstream is then run with an undefined grad_output."""
 
