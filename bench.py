@@ -256,6 +256,275 @@ def other_config_region(name, compact, rank, dev, steps=30, warmup=5):
     return out
 
 
+def _graph_us(launch, reps, rounds=7):
+    """Microseconds per launch of a small operator: `reps` back-to-back launches captured into ONE HIP graph on a side stream and replayed
+    between two HIP events recorded on that same stream (the operators launch on torch's current stream, which is the capture / replay
+    stream here); minimum and median over `rounds` replays.  A graph keeps the host out of the measurement: the per-call ctypes cost
+    (4-6 us) exceeds several of these kernels.  Falls back to events around eager launches if the capture fails."""
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            launch()
+    torch.cuda.synchronize()
+    how = "hip_graph"
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(reps):
+                launch()
+        run = graph.replay
+    except Exception:  # noqa: BLE001
+        how = "eager"
+
+        def run():
+            for _ in range(reps):
+                launch()
+    per = []
+    with torch.cuda.stream(side):
+        run()
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            run()
+            e1.record(side)
+            e1.synchronize()
+            per.append(1e3 * e0.elapsed_time(e1) / reps)
+    torch.cuda.synchronize()
+    per.sort()
+    return per[0], per[len(per) // 2], how
+
+
+def _cpu_us(fn, min_seconds=0.25, max_calls=50):
+    """One-thread wall time of the CPU restatement of the same call (microseconds, best of the repeats)."""
+    best, n, t_all = float("inf"), 0, time.perf_counter()
+    while n < max_calls and (n == 0 or time.perf_counter() - t_all < min_seconds):
+        t0 = time.perf_counter()
+        out = fn()
+        best = min(best, time.perf_counter() - t0)
+        n += 1
+    return 1e6 * best, n, out
+
+
+# FPS is a chain of m - 1 DEPENDENT selections; no byte count bounds it.  Floor per selection for ONE workgroup per cloud on gfx950, from the
+# latencies of /opt/skills/guides/MI355X_MICROARCH.md (ds_read issue->use ~50 cyc, dependent VALU ~4 cyc, VALU issue 2 cyc per wave64
+# instruction): two dependent LDS reads (the winner's key after the barrier, then its coordinates) + one LDS atomic / barrier round (~70) +
+# the ~46 dependent instructions of the selection (distance + min + max 10, four DPP steps with their hazard slots 12, readlanes + scalar
+# max 8, match + tie key 6, decode + address 10) + the issue time of the other points and waves sharing the SIMD (10 instructions per
+# point at 2 cyc).  What the kernel does beyond this model is in DESIGN.md section 7.
+def _fps_chain_floor_us(ppt, waves):
+    clk = 2 * 50 + 70 + 4 * 46 + max(0, max(1, waves // 4) * ppt - 1) * 10 * 2
+    return clk / 2400.0
+
+
+def pointops_region(dev, seed=11):
+    """Row N1 measured: every `pointnet2_batch` operator at the shapes the reference's transformer / pointmlp backbones and
+    the ShapeNet loader call it with (openpoints/models/backbone/transformer.py:251-265, layers/group_embed.py:39-57,
+    backbone/pointmlp.py:159-163 + decoder three_nn / three_interpolate, dataset/shapenet.py:368), through the C-ABI
+    (include/unipre3d_pointops.h) with pre-allocated outputs.  Per operator: microseconds per launch (HIP events around a HIP-graph replay of
+    back-to-back launches), algorithmic bytes / time against 8 TB/s -- FPS: microseconds per selection against the dependent-chain floor --,
+    the same call on oracle/pointops_oracle.c on ONE host thread (`cpu_baseline`, kind "port"), and whether the two results are bit-equal."""
+    import ctypes
+    import numpy as np
+    from oracle import pointops as opo
+    from unipre3d_amd import pointops as po
+    lib, ptr = po.load(), _lib.ptr
+    g = torch.Generator().manual_seed(seed)
+
+    def cloud(B, N):
+        d = torch.randn(B, N, 3, generator=g)
+        return (d / d.norm(dim=-1, keepdim=True) * (torch.rand(B, N, 1, generator=g) ** (1 / 3) * 0.5)).contiguous()
+
+    def stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def chk(rc):
+        if rc != 0:
+            raise RuntimeError(f"pointops C-ABI call failed with code {rc}")
+
+    ops = {}
+
+    def add(name, shape, launch, reps, alg_bytes, cpu_fn, gpu_out, equal, extra=None, atol=None):
+        us_min, us_med, how = _graph_us(launch, reps)
+        cpu_us, cpu_n, ref = _cpu_us(cpu_fn)
+        torch.cuda.synchronize()
+        got = [t.cpu().numpy() for t in gpu_out()]
+        ref = ref if isinstance(ref, tuple) else (ref,)
+        if atol is None:
+            same = all(np.array_equal(a.reshape(b.shape), b) for a, b in zip(got, ref))
+        else:
+            same = all(float(np.abs(a.reshape(b.shape) - b).max()) <= atol * max(1.0, float(np.abs(b).max())) for a, b in zip(got, ref))
+        ach = alg_bytes / 1e9 / (us_min * 1e-6)
+        e = {"shape": shape, "us": us_min, "us_median": us_med, "timing": f"{how}: {reps} back-to-back launches between two HIP events, min of 7 replays",
+             "algorithmic_bytes": alg_bytes,
+             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS},
+             "cpu_baseline": {"value": cpu_us, "unit": "us/call", "cores": 1, "kind": "port",
+                              "sample": f"the same call on oracle/pointops_oracle.c, one host thread, best of {cpu_n}"},
+             "gpu_over_cpu": cpu_us / us_min, "equals_oracle": bool(same), "equality": equal}
+        if extra:
+            e.update(extra)
+        ops[name] = e
+
+    def fps_case(name, B, N, M):
+        xyz = cloud(B, N)
+        x = xyz.to(dev)
+        out = torch.empty(B, M, dtype=torch.int32, device=dev)
+        temp = torch.empty(B, N, dtype=torch.float32, device=dev) if N > 8192 else None
+        ppt, waves = (1, 4) if N <= 256 else (2, 4) if N <= 512 else (4, 4) if N <= 1024 else (4, 8) if N <= 2048 else ((N + 1023) // 1024, 16)
+        add(name, f"{B} clouds x {N} points -> {M} samples", lambda: chk(lib.u3d_furthest_point_sampling(B, N, M, ptr(x), ptr(temp), ptr(out), stream())),
+            10, 12.0 * B * N + 4.0 * B * M, lambda: opo.furthest_point_sampling(xyz.numpy(), M), lambda: (out,), "indices bit-exact")
+        e = ops[name]
+        it = max(M - 1, 1)
+        floor = _fps_chain_floor_us(ppt, waves)
+        e["roofline"] = {"bound": "dependent_chain", "iterations": it, "achieved": e["us"] / it, "floor": floor, "unit": "us/selection",
+                         "frac": floor / (e["us"] / it),
+                         "what": "m - 1 selections, each needing the previous one's winner: priced per selection against a serial floor built from the "
+                                 "microarchitecture guide's latencies (two dependent LDS reads, one LDS-atomic + barrier round, ~46 dependent instructions, "
+                                 f"issue time of {ppt} point(s) per lane on {waves} waves)"}
+        e["us_per_selection"] = e["us"] / it
+        return x, out
+
+    # ---- transformer tokenizer (32 clouds x 1024 -> 128 groups, r = 0.1, k = 32) ----
+    B, N, M, K, C = 32, 1024, 128, 32, 384
+    fps_case("fps_1024_to_128", B, N, M)
+    xyz = cloud(B, N)
+    ctr_idx = torch.from_numpy(opo.furthest_point_sampling(xyz.numpy(), M)).long()
+    new_xyz = torch.gather(xyz, 1, ctr_idx.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    x, nx = xyz.to(dev), new_xyz.to(dev)
+    bq = torch.empty(B, M, K, dtype=torch.int32, device=dev)
+    add("ball_query", f"{B} x {M} queries over {N} points, r = 0.1, nsample = {K}",
+        lambda: chk(lib.u3d_ball_query(B, N, M, ctypes.c_float(0.1), K, ptr(nx), ptr(x), ptr(bq), stream())), 20,
+        12.0 * B * (N + M) + 4.0 * B * M * K, lambda: opo.ball_query(0.1, K, xyz.numpy(), new_xyz.numpy()), lambda: (bq,), "indices bit-exact")
+    idx_h = opo.ball_query(0.1, K, xyz.numpy(), new_xyz.numpy())
+    idx = torch.from_numpy(idx_h).to(dev)
+    for tag, c in (("xyz", 3), ("c384", C)):
+        pts = torch.randn(B, c, N, generator=g)
+        pd = pts.to(dev)
+        go = torch.empty(B, c, M, K, device=dev)
+        add(f"group_points_{tag}", f"({B},{c},{N}) gathered by ({B},{M},{K})",
+            lambda pd=pd, go=go, c=c: chk(lib.u3d_group_points(B, c, N, M, K, ptr(pd), ptr(idx), ptr(go), stream())), 20,
+            4.0 * B * c * N + 4.0 * B * M * K + 4.0 * B * c * M * K, lambda pts=pts: opo.group_points(pts.numpy(), idx_h), lambda go=go: (go,), "values bit-exact")
+    gout = torch.randn(B, C, M, K, generator=g)
+    gd, gp = gout.to(dev), torch.zeros(B, C, N, device=dev)
+
+    def group_grad():
+        gp.zero_()
+        chk(lib.u3d_group_points_grad(B, C, N, M, K, ptr(gd), ptr(idx), ptr(gp), stream()))
+    add("group_points_grad_c384", f"({B},{C},{M},{K}) scattered into ({B},{C},{N}) (incl. the zero-fill)", group_grad, 20,
+        4.0 * B * C * M * K + 4.0 * B * M * K + 2 * 4.0 * B * C * N, lambda: opo.group_points_grad(gout.numpy(), idx_h, N), lambda: (gp,),
+        "fp32 scatter-add order: <= 1e-5 of the largest value", atol=1e-5)
+    feats = torch.randn(B, C, N, generator=g)
+    fd, ci = feats.to(dev), ctr_idx.to(torch.int32).to(dev)
+    gat = torch.empty(B, C, M, device=dev)
+    add("gather_points_c384", f"({B},{C},{N}) gathered by ({B},{M})", lambda: chk(lib.u3d_gather_points(B, C, N, M, ptr(fd), ptr(ci), ptr(gat), stream())), 20,
+        4.0 * B * C * M * 2 + 4.0 * B * M, lambda: opo.gather_points(feats.numpy(), ctr_idx.numpy().astype(np.int32)), lambda: (gat,), "values bit-exact")
+
+    # ---- pointmlp (16 clouds x 2048; stages 1024 / 512 / 256 / 128; decoder 2048 <- 512) ----
+    B2 = 16
+    for n_, m_ in ((2048, 1024), (1024, 512), (512, 256), (256, 128)):
+        fps_case(f"fps_{n_}_to_{m_}", B2, n_, m_)
+    unk, kn = cloud(B2, 2048), cloud(B2, 512)
+    ud, kd = unk.to(dev), kn.to(dev)
+    d2, i3 = torch.empty(B2, 2048, 3, device=dev), torch.empty(B2, 2048, 3, dtype=torch.int32, device=dev)
+    add("three_nn", f"{B2} x 2048 unknown <- 512 known", lambda: chk(lib.u3d_three_nn(B2, 2048, 512, ptr(ud), ptr(kd), ptr(d2), ptr(i3), stream())), 20,
+        12.0 * B2 * (2048 + 512) + 24.0 * B2 * 2048, lambda: opo.three_nn(unk.numpy(), kn.numpy()), lambda: (d2, i3), "squared distances and indices bit-exact")
+    d2h, i3h = opo.three_nn(unk.numpy(), kn.numpy())
+    rec = 1.0 / (np.sqrt(d2h) + 1e-8)
+    wh = (rec / rec.sum(axis=2, keepdims=True)).astype(np.float32)
+    C2 = 256
+    kf = torch.randn(B2, C2, 512, generator=g)
+    kfd, wd, i3d = kf.to(dev), torch.from_numpy(wh).to(dev), torch.from_numpy(i3h).to(dev)
+    io = torch.empty(B2, C2, 2048, device=dev)
+    add("three_interpolate", f"({B2},{C2},512) -> ({B2},{C2},2048)", lambda: chk(lib.u3d_three_interpolate(B2, C2, 512, 2048, ptr(kfd), ptr(i3d), ptr(wd), ptr(io), stream())),
+        20, 4.0 * B2 * C2 * (512 + 2048) + 24.0 * B2 * 2048, lambda: opo.three_interpolate(kf.numpy(), i3h, wh), lambda: (io,), "values bit-exact")
+    gi = torch.randn(B2, C2, 2048, generator=g)
+    gid, gk = gi.to(dev), torch.zeros(B2, C2, 512, device=dev)
+
+    def interp_grad():
+        gk.zero_()
+        chk(lib.u3d_three_interpolate_grad(B2, C2, 2048, 512, ptr(gid), ptr(i3d), ptr(wd), ptr(gk), stream()))
+    add("three_interpolate_grad", f"({B2},{C2},2048) scattered into ({B2},{C2},512) (incl. the zero-fill)", interp_grad, 20,
+        4.0 * B2 * C2 * 2048 + 24.0 * B2 * 2048 + 2 * 4.0 * B2 * C2 * 512, lambda: opo.three_interpolate_grad(gi.numpy(), i3h, wh, 512), lambda: (gk,),
+        "fp32 scatter-add order: <= 1e-5 of the largest value", atol=1e-5)
+
+    # ---- the ShapeNet loader's call (dataset/shapenet.py:368): one raw cloud -> 1024 points ----
+    fps_case("fps_loader_8192_to_1024", 1, 8192, 1024)
+    return {"ops": ops, "contraction": "fma_llvm (default mode; the other two are covered by tests/test_gpu_pointops.py)",
+            "all_equal_oracle": all(o["equals_oracle"] for o in ops.values()),
+            "what": "row N1: the 9 pointnet2_batch entry points through the C-ABI at the reference's shapes; these operators move 0.4 - 50 MB per "
+                    "call, so all but the grouping of 384 channels are launch- / latency-bound, not HBM-bound (frac says by how much)"}
+
+
+def fusion_region(dev, seed=12):
+    """Row N4(a) measured: FeatureFusion's projection -> z-buffer -> gather chain at the transformer config's size (32 objects x 128 group
+    centres, the image branch's 384-channel 128 x 128 map: fusion/feat_fusion.py:58-131, model/gaussian_predictor.py:205-227) through the
+    C-ABI (include/unipre3d_fusion.h); CPU baseline = oracle/fusion_oracle.py (numpy restatement pinned to golden G7)."""
+    import ctypes
+    import numpy as np
+    from oracle import fusion_oracle as fo
+    from unipre3d_amd import cameras as cams
+    from unipre3d_amd import fusion as fu
+    from unipre3d_amd.standin import object_intrinsics
+    lib, ptr = fu.load(), _lib.ptr
+    g = torch.Generator().manual_seed(seed)
+    B, N, C, H, W = 32, 128, 384, 128, 128
+    d = torch.randn(B, N, 3, generator=g)
+    center = d / d.norm(dim=-1, keepdim=True) * (torch.rand(B, N, 1, generator=g) ** (1 / 3) * 0.5)
+    wv = torch.stack([cams.orbit_cameras(1, cams.OBJECT_CAMERA_DISTANCE, cams.OBJECT_FOV_DEG, cams.OBJECT_ZNEAR, cams.OBJECT_ZFAR, g)[0][0] for _ in range(B)])
+    c2w = torch.linalg.inv(wv).contiguous()
+    intr = object_intrinsics(cams.OBJECT_FOV_DEG, H)
+    fx, fy, cx, cy = (ctypes.c_float(float(v)) for v in (intr[0][0], intr[1][1], intr[0][2], intr[1][2]))
+    cam_h = fo.camera_points(center.numpy(), c2w.numpy())
+    feat = torch.randn(B, C, H, W, generator=g)
+    cam, fd = torch.from_numpy(cam_h).to(dev), feat.to(dev)
+    mapped, sel = torch.empty(B, N, C, device=dev), torch.empty(B, N, dtype=torch.int32, device=dev)
+    zbuf = torch.empty(B * H * W, dtype=torch.int32, device=dev)
+    strm = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def fwd():
+        rc = lib.u3d_zbuffer_fusion_forward(B, N, C, H, W, fx, fy, cx, cy, ptr(cam), ptr(fd), ptr(mapped), ptr(sel), ptr(zbuf), strm())
+        if rc != 0:
+            raise RuntimeError(f"u3d_zbuffer_fusion_forward failed with code {rc}")
+    us_f, us_f_med, how = _graph_us(fwd, 20)
+    feat_h = feat.numpy()
+    cpu_f, n_f, (m_ref, s_ref) = _cpu_us(lambda: fo.mapped_features(cam_h, feat_h, intr[0][0], intr[1][1], intr[0][2], intr[1][2]), max_calls=5)
+    torch.cuda.synchronize()
+    same_f = bool(np.array_equal(mapped.cpu().numpy(), m_ref) and np.array_equal(sel.cpu().numpy(), s_ref))
+    gm = torch.randn(B, N, C, generator=g)
+    gmd, gf = gm.to(dev), torch.zeros(B, C, H, W, device=dev)
+
+    def bwd_scatter():
+        rc = lib.u3d_zbuffer_fusion_backward(B, N, C, H, W, ptr(gmd), ptr(sel), ptr(gf), strm())
+        if rc != 0:
+            raise RuntimeError(f"u3d_zbuffer_fusion_backward failed with code {rc}")
+
+    def bwd():
+        gf.zero_()
+        bwd_scatter()
+    us_s, _, _ = _graph_us(bwd_scatter, 20)
+    us_b, us_b_med, _ = _graph_us(bwd, 10)
+    cpu_b, n_b, g_ref = _cpu_us(lambda: fo.mapped_grad(gm.numpy(), s_ref, B, C, H, W), max_calls=3)
+    gf.zero_(); bwd_scatter(); torch.cuda.synchronize()
+    err_b = float(np.abs(gf.cpu().numpy() - g_ref).max() / max(float(np.abs(g_ref).max()), 1e-30))
+    won = int((s_ref >= 0).sum())
+    # algorithmic bytes: points 16 B, the z-buffer's clear + atomic-min + re-read on the pixels hit, the winners' C gathered values
+    # (each its own 4-byte element of a channel plane: the map is channel-major) and the (B,N,C) output written once
+    alg_f = 16.0 * B * N * 2 + 4.0 * B * H * W + 8.0 * B * N + 4.0 * won * C + 4.0 * B * N * C + 4.0 * B * N
+    alg_s = 4.0 * won * C * 2 + 4.0 * B * N
+    alg_b = alg_s + 4.0 * B * C * H * W                       # + the zero-fill of the (B,C,H,W) gradient autograd's layout demands
+    rf = lambda by, us: {"bound": "hbm", "achieved": by / 1e9 / (us * 1e-6), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / 1e9 / (us * 1e-6) / HBM_PEAK_GBS}
+    cb = lambda us, n, what: {"value": us, "unit": "us/call", "cores": 1, "kind": "port", "sample": f"{what} (oracle/fusion_oracle.py, numpy), best of {n}"}
+    return {"shape": f"{B} objects x {N} centres, feature map ({C},{H},{W}); {won} of {B * N} points win their pixel",
+            "timing": f"{how}: back-to-back launches between two HIP events, min of 7 replays",
+            "forward": {"us": us_f, "us_median": us_f_med, "launches": "memset + zbuf_min + gather", "algorithmic_bytes": alg_f, "roofline": rf(alg_f, us_f),
+                        "cpu_baseline": cb(cpu_f, n_f, "mapped_features on the same inputs"), "gpu_over_cpu": cpu_f / us_f, "equals_oracle": same_f,
+                        "equality": "mapped features and selection bit-exact"},
+            "backward": {"us": us_b, "us_median": us_b_med, "us_scatter_kernel_alone": us_s, "launches": "zero-fill of the (B,C,H,W) gradient + scatter_grad",
+                         "algorithmic_bytes": alg_b, "roofline": rf(alg_b, us_b), "scatter_alone_roofline": rf(alg_s, us_s),
+                         "cpu_baseline": cb(cpu_b, n_b, "mapped_grad on the same inputs"), "gpu_over_cpu": cpu_b / us_b,
+                         "rel_max_err_vs_oracle": err_b, "equals_oracle": err_b < 1e-6, "equality": "<= 1e-6 (scatter-add order)"},
+            "what": "row N4(a): 3 launches forward, no host synchronisation (the reference: ~20 ops and two .item() / nonzero syncs)"}
+
+
 def e2e_region(a, batch, dev, world, rank, B, V, H, W, loss_kind, timed):
     """One END-TO-END synthetic pre-training step: stand-in transformer predictor (unipre3d_amd/standin.py: FPS + ball query +
     grouping (N1), tokenizer, 16 blocks, 2D->3D fusion (N4), final MLP; 29.46 M parameters like the reference) -> hot path
@@ -464,6 +733,8 @@ def main():
                          "DDP all-reduce over RCCL -- use it at every N of a scaling series to get the curve of the step with the exchange in it)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the hot-only steps of C3 / C4 / C5 / C2-compact (`other_configs`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the N1 (`pointops`) and N4a (`fusion`) regions")
+    ap.add_argument("--next-rows-only", action="store_true", help="ONLY the N1 / N4a regions (profiling runs: rocprofv3 of this prints their kernels alone)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     a = ap.parse_args()
 
@@ -477,6 +748,13 @@ def main():
             print(f"[bench] WORLD_SIZE={world} but --gpus {a.gpus}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     dev = torch.device("cuda", torch.cuda.current_device())
+    if a.next_rows_only:
+        if rank == 0:
+            print(json.dumps({"pointops": pointops_region(dev), "fusion": fusion_region(dev)}), flush=True)
+        if world > 1:
+            dp.host_barrier()
+            dp.shutdown()
+        return
     cfg = synthetic.CONFIGS[a.config]
     B, P, V, H, W, level = cfg["B"], cfg["P"], cfg["V"], cfg["H"], cfg["W"], cfg["level"]
     host_batch = synthetic.make_batch(B, P, V, H, W, level=level, seed=42 + rank, compact=a.compact)
@@ -854,6 +1132,14 @@ def main():
                 oc[key] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()
         extras["other_configs"] = oc
+
+    if rank == 0 and not (a.hot_only or a.no_next_rows):
+        # rows N1 and N4(a): per-operator throughput, roofline and CPU-oracle baseline; ~3 s together
+        for key, fn in (("pointops", pointops_region), ("fusion", fusion_region)):
+            try:
+                extras[key] = fn(dev)
+            except Exception as e:  # noqa: BLE001
+                extras[key] = {"error": repr(e)[:300]}
 
     watchdog.cancel()
     if rank == 0:

@@ -25,6 +25,23 @@ def test_camera_points_and_pixels_match_reference_on_cpu(golden):
         assert np.array_equal(cp[..., 2], g[f"{tag}_depth"])
 
 
+def test_fusion_oracle_is_pinned_to_the_reference_module(golden):
+    """oracle/fusion_oracle.py (the checker and the bench's CPU baseline for row N4a) == the reference module's own outputs."""
+    from oracle import fusion_oracle as fo
+    g = golden("g7_feature_fusion.npz")
+    for tag in ("sq", "rect"):
+        intr = g[f"{tag}_intr"]
+        cam = fo.camera_points(g[f"{tag}_center"], g[f"{tag}_c2w"])
+        pix, depth = fo.pixels(cam, intr[0, 0], intr[1, 1], intr[0, 2], intr[1, 2])
+        assert np.array_equal(pix, g[f"{tag}_pix"]) and np.array_equal(depth, g[f"{tag}_depth"])
+        assert np.array_equal(fo.fuse(g[f"{tag}_x"], g[f"{tag}_center"], g[f"{tag}_feat"], g[f"{tag}_c2w"], intr), g[f"{tag}_out"])
+        B, C, H, W = g[f"{tag}_feat"].shape
+        mapped, sel = fo.mapped_features(cam, g[f"{tag}_feat"], intr[0, 0], intr[1, 1], intr[0, 2], intr[1, 2])
+        N, Cx = mapped.shape[1], g[f"{tag}_x"].shape[2]
+        gfeat = fo.mapped_grad(g[f"{tag}_w"][:, -N:, Cx:], sel, B, C, H, W)
+        assert rel_l2(gfeat, g[f"{tag}_gfeat"]) < 1e-6
+
+
 def test_fusion_library_exports():
     from unipre3d_amd import fusion
     hdr = open(os.path.join(ROOT, "include", "unipre3d_fusion.h")).read()

@@ -111,3 +111,44 @@ def test_three_interpolate_forward_backward():
     wt = (rec / rec.sum(dim=2, keepdim=True)).numpy()
     ref = po.three_interpolate(kf, ix, wt)
     assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+def test_gradient_kernels_beyond_the_lds_rows():
+    """The scatter-add gradients accumulate channel rows in LDS (round 5); rows that do not fit 64 KB (n resp. m > 16384) take the
+    global-atomic form, and a shape whose channel count is not a multiple of the rows per workgroup exercises the tail."""
+    from unipre3d_amd import pointops
+    rng = np.random.RandomState(5)
+    for (C, N, M, K) in ((3, 20000, 40, 8), (37, 700, 33, 5), (20, 16384, 16, 4)):
+        pts = rng.randn(2, C, N).astype(np.float32)
+        idx = rng.randint(0, N, (2, M, K)).astype(np.int32)
+        idx[:, :, K // 2:] = idx[:, :, :1]                                   # ball-query style padding: many duplicates
+        f = torch.from_numpy(pts).cuda().requires_grad_(True)
+        out = pointops.grouping_operation(f, torch.from_numpy(idx).cuda())
+        assert np.array_equal(out.detach().cpu().numpy(), po.group_points(pts, idx))
+        go = rng.randn(*out.shape).astype(np.float32)
+        out.backward(torch.from_numpy(go).cuda())
+        gref = po.group_points_grad(go, idx, N)
+        assert np.abs(f.grad.cpu().numpy() - gref).max() <= 1e-5 * max(np.abs(gref).max(), 1.0)
+    for (C, n, m) in ((5, 300, 17000), (19, 1000, 50)):
+        feats = rng.randn(2, C, m).astype(np.float32)
+        idx = rng.randint(0, m, (2, n, 3)).astype(np.int32)
+        w = rng.rand(2, n, 3).astype(np.float32)
+        f = torch.from_numpy(feats).cuda().requires_grad_(True)
+        out = pointops.three_interpolate(f, torch.from_numpy(idx).cuda(), torch.from_numpy(w).cuda())
+        go = rng.randn(*out.shape).astype(np.float32)
+        out.backward(torch.from_numpy(go).cuda())
+        gref = po.three_interpolate_grad(go, idx, w, m)
+        assert np.abs(f.grad.cpu().numpy() - gref).max() <= 1e-5 * max(np.abs(gref).max(), 1.0)
+
+
+def test_fps_degenerate_clouds():
+    """All points identical (every distance 0: the tie key alone decides, padding slots must never win), more samples than points,
+    and sizes straddling every register-slot configuration of the kernel."""
+    from unipre3d_amd import pointops
+    same = np.zeros((2, 300, 3), np.float32) + np.float32(0.25)
+    got = pointops.furthest_point_sample(torch.from_numpy(same).cuda(), 40).cpu().numpy()
+    assert np.array_equal(got, po.furthest_point_sampling(same, 40))
+    for N, M in ((255, 255), (256, 64), (257, 64), (513, 100), (1025, 100), (2049, 70), (4097, 50), (8192, 40), (8193, 20), (64, 64), (3, 3)):
+        xyz = _cloud(2, N, seed=N + 1, grid=(N % 2 == 1))
+        got = pointops.furthest_point_sample(torch.from_numpy(xyz).cuda(), M).cpu().numpy()
+        assert np.array_equal(got, po.furthest_point_sampling(xyz, M)), (N, M)

@@ -1,14 +1,14 @@
 // Point sampling / grouping operators for gfx950; semantics: oracle/pointops_oracle.c, which restates
 // openpoints/cpp/pointnet2_batch/src/{sampling,ball_query,group_points}_gpu.cu.
 //
-//  * furthest point sampling: one 256- or 1024-thread workgroup per cloud, coordinates staged once in LDS, up to 32 points per
-//    thread with their running minimum distances in REGISTERS (the reference round-trips a (B,N) temp array through
-//    global memory every iteration), arg-max over (distance, inverted tie key): DPP row steps + 4 readlanes within the
-//    wave, 4 wave results through double-buffered LDS => ONE barrier per selected point.  The tie key reproduces the order in which the
-//    reference's shared-memory tree resolves equal distances for ITS block size, so the selection is bit-identical.
+//  * furthest point sampling: one workgroup per cloud, coordinates staged once in LDS, up to 8 points per thread with their running
+//    minimum distances in REGISTERS (the reference round-trips a (B,N) temp array through global memory every iteration); the
+//    selection's critical path is described at fps_kernel.  The tie key reproduces the order in which the reference's shared-memory
+//    tree resolves equal distances for ITS block size, so the selection is bit-identical.
 //  * ball query: one WAVE per query (the reference: one thread per query scanning all N points serially): 64 candidates
 //    per step, ballot + popcount prefix keeps index order, early exit at nsample.
-//  * group / gather (+grad): one thread per output element, coalesced on the output side.
+//  * group / gather: four outputs per thread, indices in registers across 8 channels; gradients: channel rows accumulated in LDS.
+//  * three_nn: a DPP quad per query over an LDS-staged known cloud; three_interpolate (+grad): indices / weights loaded once per point.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -17,23 +17,47 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// workgroup sizes of the furthest-point-sampling kernel (experiments: make EXTRA=-DU3D_FPS_BIG_THREADS=512 LIBDIR=../lib_x)
+#ifndef U3D_FPS_SMALL_THREADS
+#define U3D_FPS_SMALL_THREADS 256    // clouds of <= 1024 points
+#endif
+#ifndef U3D_FPS_PK
+#define U3D_FPS_PK 1                 // two points per v_pk_*_f32 instruction in the distance update
+#endif
+#ifndef U3D_FPS_BIG_THREADS
+#define U3D_FPS_BIG_THREADS 1024     // clouds of <= 8192 points
+#endif
+
 // `a*a + b*b + c*c` and `w0*p0 + w1*p1 + w2*p2` as the reference's kernels write them (sampling_gpu.cu:140, ball_query_gpu.cu:38,
 // interpolate_gpu.cu:40, :103) are compiled by nvcc with -fmad=true: WHICH product is rounded on its own before the two fused
 // multiply-adds decides ties, and FPS is a chaotic integer selection -- so the contraction is a call-time mode
-// (u3d_pointops_set_contraction), bit-exact against oracle/pointops_oracle.c in every mode:
+// (u3d_pointops_set_contraction; a template parameter of every kernel, so the hot loops carry no mode branch), bit-exact against
+// oracle/pointops_oracle.c in every mode:
 //   U3D_PO_FMA_LLVM (default)  fma(c, c, fma(a, a, b*b))  what LLVM's DAG combiner -- NVVM is LLVM -- makes of fadd(fadd(fmul, fmul), fmul):
 //                              the FIRST operand's multiply is folded into the inner add, the second product stays a rounded fmul
 //   U3D_PO_FMA_CHAIN           fma(c, c, fma(b, b, a*a))  rounds 1-3's reading (left-to-right chain, first product rounded)
 //   U3D_PO_NO_FMA              ((a*a + b*b) + c*c) with every product rounded: -fmad=false
-__device__ __forceinline__ float sum3(float a0, float a1, float b0, float b1, float c0, float c1, int cm) {   // a0*a1 + b0*b1 + c0*c1
+template <int CM>
+__device__ __forceinline__ float sum3(float a0, float a1, float b0, float b1, float c0, float c1) {   // a0*a1 + b0*b1 + c0*c1
 #pragma clang fp contract(off)   // (only the fmaf calls below fuse; HIP's __fmul_rn / __fadd_rn are plain operators the optimiser may contract)
-  if (cm == U3D_PO_FMA_LLVM) return fmaf(c0, c1, fmaf(a0, a1, b0 * b1));
-  if (cm == U3D_PO_FMA_CHAIN) return fmaf(c0, c1, fmaf(b0, b1, a0 * a1));
+  if (CM == U3D_PO_FMA_LLVM) return fmaf(c0, c1, fmaf(a0, a1, b0 * b1));
+  if (CM == U3D_PO_FMA_CHAIN) return fmaf(c0, c1, fmaf(b0, b1, a0 * a1));
   return (a0 * a1 + b0 * b1) + c0 * c1;
 }
-__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz, int cm) {
+// the same sum for TWO points at once: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 round each half exactly like the scalar forms
+template <int CM>
+__device__ __forceinline__ f32x2 sum3_pk(f32x2 a, f32x2 b, f32x2 c) {   // a*a + b*b + c*c
+#pragma clang fp contract(off)
+  if (CM == U3D_PO_FMA_LLVM) return __builtin_elementwise_fma(c, c, __builtin_elementwise_fma(a, a, b * b));
+  if (CM == U3D_PO_FMA_CHAIN) return __builtin_elementwise_fma(c, c, __builtin_elementwise_fma(b, b, a * a));
+  return (a * a + b * b) + c * c;
+}
+template <int CM>
+__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz) {
   const float dx = bx - ax, dy = by - ay, dz = bz - az;
-  return sum3(dx, dx, dy, dy, dz, dz, cm);
+  return sum3<CM>(dx, dx, dy, dy, dz, dz);
 }
 int g_contraction = U3D_PO_FMA_LLVM;   // host: mode of the launches that follow (process-wide, like a build flag of the reference)
 
@@ -46,29 +70,25 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return v;
 }
 
-// (distance, inverted tie key) arg-max across the wave without the LDS crossbar: four DPP steps leave every lane with
-// its 16-lane row's winner, the four row winners are read into SGPRs and compared on the scalar unit.
+// maximum of a 32-bit key over the wave, returned in a scalar register: four DPP steps leave every lane with its 16-lane row's maximum
+// (v_max_u32 with a DPP operand: one instruction per step), the four row results are read into SGPRs and combined on the scalar unit
 template <int CTRL>
-__device__ __forceinline__ void dpp_max_step(float& d, uint32_t& t) {
-  const float od = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), CTRL, 0xf, 0xf, false));
-  const uint32_t ot = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, CTRL, 0xf, 0xf, false);
-  const bool take = od > d || (od == d && ot > t);
-  d = take ? od : d;
-  t = take ? ot : t;
+__device__ __forceinline__ uint32_t dpp_max_step(uint32_t v) {
+  const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+  return o > v ? o : v;
 }
-__device__ __forceinline__ unsigned long long wave_argmax(float d, uint32_t t) {
-  dpp_max_step<0xB1>(d, t);    // quad_perm [1,0,3,2]
-  dpp_max_step<0x4E>(d, t);    // quad_perm [2,3,0,1]
-  dpp_max_step<0x141>(d, t);   // row_half_mirror
-  dpp_max_step<0x140>(d, t);   // row_mirror
-  unsigned long long best = 0ull;
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = dpp_max_step<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_max_step<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_max_step<0x141>(v);   // row_half_mirror
+  v = dpp_max_step<0x140>(v);   // row_mirror
+  uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const unsigned long long k = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(__float_as_int(d), r * 16) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readlane((int)t, r * 16);
-    best = k > best ? k : best;
+  for (int q = 1; q < 4; ++q) {
+    const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)v, q * 16);
+    r = u > r ? u : r;
   }
-  return best;
+  return r;
 }
 
 // tie key of point k for the reference's block size bs = 2^lg (lg <= 10): equal distances are won by the smaller
@@ -83,58 +103,88 @@ __device__ __forceinline__ int fps_decode(uint32_t tk, int lg) {
   return (int)((q << lg) + (lg ? (__brev(r) >> (32 - lg)) : 0u));
 }
 
-template <int FPS_THREADS, int PPT>
-__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int lg, int cm, const float* __restrict__ dataset,
+// Furthest point sampling is m - 1 DEPENDENT selections, so what is optimised is the length of one selection's critical path (round 5;
+// rounds 1-4: 0.7 - 2.7 us per selection, a (distance, key) pair carried through every compare and a mode branch in the loop):
+//   * squared distances are >= +0, so their IEEE bit patterns order like unsigned integers: the running minimum is v_min_u32, the
+//     per-lane and per-wave maxima v_max3_u32 / v_max_u32 with a DPP operand -- no (distance, tie key) pair in the scan at all;
+//   * two points per instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) for the distance itself;
+//   * only once the wave's maximum is known does the wave ask WHICH of its points holds it: one v_cmp_eq per register slot gives a
+//     lane mask in SGPRs, and the tie key of every set bit is computed from (wave, lane, slot) on the SCALAR unit (usually one bit);
+//   * the waves' (maximum, inverted tie key) pairs meet in ONE ds_max_u64 per wave on a triple-buffered LDS word (slot j mod 3 is
+//     used by selection j and cleared during selection j - 1), one barrier per selection, every lane reads the winner back.
+// The tie key reproduces the order in which the reference's shared-memory tree resolves equal distances for ITS block size.
+template <int FPS_THREADS, int PPT, int CM>
+__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int lg, const float* __restrict__ dataset,
                                                           int32_t* __restrict__ idxs) {
-  constexpr int FPS_WAVES = FPS_THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) float s_xyz[];   // [n][3]
-  __shared__ unsigned long long s_key[2][FPS_WAVES];
-  const int bi = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  __shared__ unsigned long long s_best[3];
+  const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63);
   const float* ds = dataset + (size_t)bi * n * 3;
   int32_t* out = idxs + (size_t)bi * m;
   for (int i = tid; i < n * 3; i += FPS_THREADS) s_xyz[i] = ds[i];
+  if (tid < 3) s_best[tid] = 0ull;
   __syncthreads();
   const uint32_t bs = 1u << lg;
-  float x[PPT], y[PPT], z[PPT], t[PPT];
-  uint32_t inv_tk[PPT];
+  float x[PPT], y[PPT], z[PPT];
+  uint32_t t[PPT];                                   // running minimum squared distance, as its bit pattern
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     const int k = tid + i * FPS_THREADS;
     const bool v = k < n;
     x[i] = v ? s_xyz[k * 3] : 0.f; y[i] = v ? s_xyz[k * 3 + 1] : 0.f; z[i] = v ? s_xyz[k * 3 + 2] : 0.f;
-    t[i] = v ? 1e10f : 0.f;                        // padding slots: distance 0 and the lowest key, never beat a real point
-    inv_tk[i] = v ? 0xFFFFFFFFu - fps_tie_key((uint32_t)k, lg, bs) : 0u;
+    t[i] = v ? __float_as_uint(1e10f) : 0u;          // padding slots: distance 0, and never a candidate below (k >= n)
   }
-  int old = 0;
+  int old = 0, cur = 1, nxt = 2;
   if (tid == 0) out[0] = 0;
   for (int j = 1; j < m; ++j) {
     const float ox = s_xyz[old * 3], oy = s_xyz[old * 3 + 1], oz = s_xyz[old * 3 + 2];
-    float bd = -1.f;
-    uint32_t bt = 0u;
+    uint32_t lmax = 0u;
+    if constexpr (PPT == 1 || PPT > 4 || !U3D_FPS_PK) {   // (packed math measured 4 % ahead at 4 points per lane, 3 % behind at 8)
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const float d = dist2(ox, oy, oz, x[i], y[i], z[i], cm);
-      t[i] = fminf(d, t[i]);
-      const bool take = t[i] > bd || (t[i] == bd && inv_tk[i] > bt);
-      bd = take ? t[i] : bd;
-      bt = take ? inv_tk[i] : bt;
+      for (int i = 0; i < PPT; ++i) {
+        t[i] = min(t[i], __float_as_uint(dist2<CM>(ox, oy, oz, x[i], y[i], z[i])));
+        lmax = max(lmax, t[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PPT; i += 2) {
+#pragma clang fp contract(off)
+        const f32x2 dx = f32x2{x[i], x[i + 1]} - ox, dy = f32x2{y[i], y[i + 1]} - oy, dz = f32x2{z[i], z[i + 1]} - oz;
+        const f32x2 d = sum3_pk<CM>(dx, dy, dz);
+        t[i] = min(t[i], __float_as_uint(d.x));
+        t[i + 1] = min(t[i + 1], __float_as_uint(d.y));
+        lmax = max(lmax, max(t[i], t[i + 1]));
+      }
     }
-    const unsigned long long best = wave_argmax(bd, bt);
-    if (lane == 0) s_key[j & 1][wave] = best;
+    const uint32_t wmax = wave_max_u32(lmax);
+    uint32_t btk = 0u;                               // largest inverted tie key among this wave's points at distance wmax
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {                  // (all compares first + one combined test measured slower: 61 vs 56 us at 1024 -> 128)
+      unsigned long long mk = __ballot(t[i] == wmax);
+      while (mk) {
+        const uint32_t k = wave_base + (uint32_t)__builtin_ctzll(mk) + (uint32_t)(i * FPS_THREADS);
+        mk &= mk - 1ull;
+        if (k < (uint32_t)n) {
+          const uint32_t tk = ~fps_tie_key(k, lg, bs);
+          btk = tk > btk ? tk : btk;
+        }
+      }
+    }
+    if (lane == 0) atomicMax(&s_best[cur], ((unsigned long long)wmax << 32) | btk);
+    if (tid == 0) s_best[nxt] = 0ull;
     __syncthreads();
-    unsigned long long w = s_key[j & 1][0];
-#pragma unroll
-    for (int q = 1; q < FPS_WAVES; ++q) {
-      const unsigned long long u = s_key[j & 1][q];
-      w = u > w ? u : w;
-    }
-    old = fps_decode(0xFFFFFFFFu - (uint32_t)w, lg);
+    const unsigned long long w = s_best[cur];
+    old = fps_decode(~(uint32_t)w, lg);
     if (tid == 0) out[j] = old;
+    cur = nxt;
+    nxt = nxt == 2 ? 0 : nxt + 1;
   }
 }
 
 // generic path for clouds larger than FPS_THREADS*8 points: minimum distances in global scratch
-__global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int lg, int cm, const float* __restrict__ dataset,
+template <int CM>
+__global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int lg, const float* __restrict__ dataset,
                                                          float* __restrict__ temp, int32_t* __restrict__ idxs) {
   constexpr int FPS_THREADS = 1024, FPS_WAVES = 16;
   __shared__ unsigned long long s_key[2][FPS_WAVES];
@@ -150,7 +200,7 @@ __global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int lg, i
     const float ox = ds[old * 3], oy = ds[old * 3 + 1], oz = ds[old * 3 + 2];
     unsigned long long best = 0ull;
     for (int k = tid; k < n; k += FPS_THREADS) {
-      const float d = dist2(ox, oy, oz, ds[k * 3], ds[k * 3 + 1], ds[k * 3 + 2], cm);
+      const float d = dist2<CM>(ox, oy, oz, ds[k * 3], ds[k * 3 + 1], ds[k * 3 + 2]);
       const float d2 = fminf(d, tp[k]);
       tp[k] = d2;
       const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (0xFFFFFFFFu - fps_tie_key((uint32_t)k, lg, bs));
@@ -170,7 +220,8 @@ __global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int lg, i
   }
 }
 
-__global__ __launch_bounds__(256) void ball_query_kernel(int n, int m, int total_q, float radius2, int nsample, int cm,
+template <int CM>
+__global__ __launch_bounds__(256) void ball_query_kernel(int n, int m, int total_q, float radius2, int nsample,
                                                          const float* __restrict__ new_xyz, const float* __restrict__ xyz,
                                                          int32_t* __restrict__ idx) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -187,7 +238,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(int n, int m, int total
     bool in = false;
     if (k < n) {
       const float dx = qx - pts[k * 3], dy = qy - pts[k * 3 + 1], dz = qz - pts[k * 3 + 2];
-      in = sum3(dx, dx, dy, dy, dz, dz, cm) < radius2;
+      in = sum3<CM>(dx, dx, dy, dy, dz, dz) < radius2;
     }
     const unsigned long long bal = __ballot(in);
     if (bal) {
@@ -202,72 +253,152 @@ __global__ __launch_bounds__(256) void ball_query_kernel(int n, int m, int total
   for (int l = cnt + lane; l < nsample; l += 64) o[l] = pad;
 }
 
-__global__ void group_points_kernel(int c, int n, int npoints, int nsample, const float* __restrict__ points,
-                                    const int32_t* __restrict__ idx, float* __restrict__ out) {
+// group / gather: out[b][c][e] = points[b][c][idx[b][e]].  A thread owns FOUR consecutive outputs and walks GP_CH channels with their
+// indices in registers (one 16-byte index load, then per channel four gathers from a row that sits in cache and one 16-byte store);
+// the scalar kernel serves shapes / pointers the vector form cannot (total % 4 != 0, unaligned bases).
+constexpr int GP_CH = 8;
+__global__ __launch_bounds__(256) void group_points_vec_kernel(int c, int n, int total, const float* __restrict__ points,
+                                                               const int32_t* __restrict__ idx, float* __restrict__ out) {
+  const int bi = blockIdx.z, c0 = blockIdx.y * GP_CH;
+  const int e0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e0 >= total) return;
+  const int4 id = *reinterpret_cast<const int4*>(idx + (size_t)bi * total + e0);
+  const int c1 = min(c, c0 + GP_CH);
+#pragma unroll 4
+  for (int ci = c0; ci < c1; ++ci) {
+    const float* row = points + ((size_t)bi * c + ci) * n;
+    *reinterpret_cast<float4*>(out + ((size_t)bi * c + ci) * total + e0) = make_float4(row[id.x], row[id.y], row[id.z], row[id.w]);
+  }
+}
+__global__ void group_points_kernel(int c, int n, int total, const float* __restrict__ points, const int32_t* __restrict__ idx,
+                                    float* __restrict__ out) {
   const int bi = blockIdx.z, ci = blockIdx.y;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= npoints * nsample) return;
-  const int src = idx[(size_t)bi * npoints * nsample + e];
-  out[((size_t)bi * c + ci) * npoints * nsample + e] = points[((size_t)bi * c + ci) * n + src];
+  if (e >= total) return;
+  const int src = idx[(size_t)bi * total + e];
+  out[((size_t)bi * c + ci) * total + e] = points[((size_t)bi * c + ci) * n + src];
 }
 
-__global__ void group_points_grad_kernel(int c, int n, int npoints, int nsample, const float* __restrict__ grad_out,
+// group / gather gradient: grad_points[b][c][idx[b][e]] += grad_out[b][c][e].  The reference (and rounds 1-4 here) issue one GLOBAL float
+// atomic per element; ball-query index sets repeat their first hit as padding, so thousands of them land on one address (3.0 ms at
+// the transformer shape).  Here a workgroup owns `cb` channel rows of one cloud in LDS ([cb][n] floats), accumulates with LDS atomics
+// (an index is loaded once and reused by the cb channels) and adds the finished rows to grad_points with plain coalesced
+// read-modify-writes: every output element belongs to exactly one workgroup.
+template <int CB>
+__global__ __launch_bounds__(256) void group_points_grad_lds_kernel(int c, int n, int total, const float* __restrict__ grad_out,
+                                                                    const int32_t* __restrict__ idx, float* __restrict__ grad_points) {
+  extern __shared__ __attribute__((aligned(16))) float s_acc[];   // [CB][n]
+  const int bi = blockIdx.y, c0 = blockIdx.x * CB;
+  const int nc = min(CB, c - c0);
+  for (int i = threadIdx.x; i < nc * n; i += 256) s_acc[i] = 0.f;
+  __syncthreads();
+  const int32_t* ip = idx + (size_t)bi * total;
+  const float* go = grad_out + ((size_t)bi * c + c0) * total;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int dst = ip[e];
+    float g[CB];                                    // all loads of the step in flight before the first LDS atomic
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) g[cc] = cc < nc ? go[(size_t)cc * total + e] : 0.f;
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc)
+      if (cc < nc) unsafeAtomicAdd(&s_acc[cc * n + dst], g[cc]);
+  }
+  __syncthreads();
+  float* gp = grad_points + ((size_t)bi * c + c0) * n;
+  const int len = nc * n;
+  for (int i0 = threadIdx.x; i0 < len; i0 += 256 * 4) {
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = i0 + q * 256 < len ? gp[i0 + q * 256] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (i0 + q * 256 < len) gp[i0 + q * 256] = v[q] + s_acc[i0 + q * 256];
+  }
+}
+__global__ void group_points_grad_kernel(int c, int n, int total, const float* __restrict__ grad_out,
                                          const int32_t* __restrict__ idx, float* __restrict__ grad_points) {
   const int bi = blockIdx.z, ci = blockIdx.y;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= npoints * nsample) return;
-  const int dst = idx[(size_t)bi * npoints * nsample + e];
-  unsafeAtomicAdd(&grad_points[((size_t)bi * c + ci) * n + dst], grad_out[((size_t)bi * c + ci) * npoints * nsample + e]);
+  if (e >= total) return;
+  const int dst = idx[(size_t)bi * total + e];
+  unsafeAtomicAdd(&grad_points[((size_t)bi * c + ci) * n + dst], grad_out[((size_t)bi * c + ci) * total + e]);
 }
 
 // ---- three_nn / three_interpolate (+grad): interpolate_gpu.cu:16-140 ------------------------------------------------------
 // three_nn: the reference gives every query a thread that streams all m known points from global memory.  Here a workgroup
-// stages the known cloud through LDS in tiles (one coalesced copy per tile, then every lane reads the SAME LDS word per step:
-// a broadcast, no bank conflicts) and each lane keeps its query's running three best in registers.  Scanning in index order
-// with the reference's strict `<` insertions gives the three smallest (distance, index) pairs in lexicographic order, ties to
-// the lower index -- reproduced exactly; an unfilled slot keeps the reference's initial 1e40 (stored as +inf) / index 0.
-constexpr int NN_THREADS = 128;
+// stages the known cloud through LDS in tiles and FOUR lanes (a DPP quad) share one query: lane s of the quad scans the known points
+// s, s + 4, s + 8, ... of the tile (the quad reads 12 consecutive LDS words per step: no bank conflict, 16 quads broadcast), keeps
+// its running three best in registers behind a single `d < best3` guard, and the four sorted triples are merged at the end with two
+// quad_perm exchanges.  The reference's scan in index order with strict `<` insertions yields the three smallest (distance, index)
+// pairs in lexicographic order; the merge compares exactly that pair, so any partition of the indices gives the same answer --
+// bit-exact, ties to the lower index; an unfilled slot keeps the reference's initial 1e40 (stored as +inf) / index 0.
+constexpr int NN_THREADS = 256, NN_SPLIT = 4, NN_Q = NN_THREADS / NN_SPLIT;
 constexpr int NN_TILE = 2048;   // known points per LDS tile: 24 KB
-__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(int n, int m, int cm, const float* __restrict__ unknown,
+struct Best3 { float d1, d2, d3; int i1, i2, i3; };
+__device__ __forceinline__ void nn_insert_lex(Best3& b, float d, int k) {   // (d, k) into the sorted triple, lexicographic order
+  const bool l1 = d < b.d1 || (d == b.d1 && k < b.i1);
+  const bool l2 = d < b.d2 || (d == b.d2 && k < b.i2);
+  const bool l3 = d < b.d3 || (d == b.d3 && k < b.i3);
+  b.d3 = l2 ? b.d2 : (l3 ? d : b.d3); b.i3 = l2 ? b.i2 : (l3 ? k : b.i3);
+  b.d2 = l1 ? b.d1 : (l2 ? d : b.d2); b.i2 = l1 ? b.i1 : (l2 ? k : b.i2);
+  b.d1 = l1 ? d : b.d1;               b.i1 = l1 ? k : b.i1;
+}
+template <int CTRL>
+__device__ __forceinline__ void nn_merge_step(Best3& b) {
+  const auto xf = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); };
+  const auto xi = [](int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); };
+  const float o1 = xf(b.d1), o2 = xf(b.d2), o3 = xf(b.d3);
+  const int j1 = xi(b.i1), j2 = xi(b.i2), j3 = xi(b.i3);
+  nn_insert_lex(b, o1, j1);
+  nn_insert_lex(b, o2, j2);
+  nn_insert_lex(b, o3, j3);
+}
+template <int CM>
+__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(int n, int m, const float* __restrict__ unknown,
                                                               const float* __restrict__ known, float* __restrict__ dist2,
                                                               int32_t* __restrict__ idx) {
   __shared__ float s_k[NN_TILE * 3];
   const int bi = blockIdx.y;
-  const int pt = blockIdx.x * NN_THREADS + threadIdx.x;
+  const int pt = blockIdx.x * NN_Q + (threadIdx.x >> 2), sub = threadIdx.x & 3;
   const bool live = pt < n;
   const float* u = unknown + ((size_t)bi * n + (live ? pt : 0)) * 3;
   const float ux = u[0], uy = u[1], uz = u[2];
   const float* kb = known + (size_t)bi * m * 3;
-  double best1 = 1e40, best2 = 1e40, best3 = 1e40;
-  int i1 = 0, i2 = 0, i3 = 0;
+  const float inf = __builtin_inff();                  // (float)1e40: what the reference's `double best = 1e40` becomes when stored
+  Best3 b{inf, inf, inf, 0, 0, 0};
   for (int k0 = 0; k0 < m; k0 += NN_TILE) {
     const int cnt = min(NN_TILE, m - k0);
     __syncthreads();
     for (int e = threadIdx.x; e < cnt * 3; e += NN_THREADS) s_k[e] = kb[(size_t)k0 * 3 + e];
     __syncthreads();
-    for (int j = 0; j < cnt; ++j) {
+    for (int j = sub; j < cnt; j += NN_SPLIT) {
       const float dx = ux - s_k[j * 3], dy = uy - s_k[j * 3 + 1], dz = uz - s_k[j * 3 + 2];
-      const float d = sum3(dx, dx, dy, dy, dz, dz, cm);   // (ux-x)^2 + (uy-y)^2 + (uz-z)^2 in the selected contraction
-      const int k = k0 + j;
-      if (d < best1) { best3 = best2; i3 = i2; best2 = best1; i2 = i1; best1 = d; i1 = k; }
-      else if (d < best2) { best3 = best2; i3 = i2; best2 = d; i2 = k; }
-      else if (d < best3) { best3 = d; i3 = k; }
+      const float d = sum3<CM>(dx, dx, dy, dy, dz, dz);   // (ux-x)^2 + (uy-y)^2 + (uz-z)^2 in the selected contraction
+      if (d < b.d3) {                                     // ascending indices within a lane: the reference's strict `<` insertions
+        const int k = k0 + j;
+        const bool l1 = d < b.d1, l2 = d < b.d2;
+        b.d3 = l2 ? b.d2 : d;                 b.i3 = l2 ? b.i2 : k;
+        b.d2 = l1 ? b.d1 : (l2 ? d : b.d2);   b.i2 = l1 ? b.i1 : (l2 ? k : b.i2);
+        b.d1 = l1 ? d : b.d1;                 b.i1 = l1 ? k : b.i1;
+      }
     }
   }
-  if (live) {
+  nn_merge_step<0xB1>(b);   // quad_perm [1,0,3,2]
+  nn_merge_step<0x4E>(b);   // quad_perm [2,3,0,1]
+  if (live && sub == 0) {
     float* od = dist2 + ((size_t)bi * n + pt) * 3;
     int32_t* oi = idx + ((size_t)bi * n + pt) * 3;
-    od[0] = (float)best1; od[1] = (float)best2; od[2] = (float)best3;
-    oi[0] = i1; oi[1] = i2; oi[2] = i3;
+    od[0] = b.d1; od[1] = b.d2; od[2] = b.d3;
+    oi[0] = b.i1; oi[1] = b.i2; oi[2] = b.i3;
   }
 }
 
 // three_interpolate: the reference launches one thread per (batch, channel, point), so every channel re-reads the point's three
 // indices and weights.  Here a lane owns a point, loads them once and walks IC_CH channels: three gathers from the channel's
-// row of m values (cache-resident) and one coalesced store per channel.  out = w0 p[i0] + w1 p[i1] + w2 p[i2], contracted
-// left to right like nvcc does (fma(w2, p2, fma(w1, p1, w0 p0))).
+// row of m values (cache-resident) and one coalesced store per channel.  out = w0 p[i0] + w1 p[i1] + w2 p[i2] in the selected contraction.
 constexpr int IC_CH = 8;
-__global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, int n, int cm, const float* __restrict__ points,
+template <int CM>
+__global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, int n, const float* __restrict__ points,
                                                                 const int32_t* __restrict__ idx, const float* __restrict__ weight,
                                                                 float* __restrict__ out) {
   const int bi = blockIdx.z, c0 = blockIdx.y * IC_CH;
@@ -277,13 +408,59 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, in
   const float* wp = weight + ((size_t)bi * n + pt) * 3;
   const int i0 = ip[0], i1 = ip[1], i2 = ip[2];
   const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
-  const int c1 = min(c, c0 + IC_CH);
-  for (int ci = c0; ci < c1; ++ci) {
-    const float* row = points + ((size_t)bi * c + ci) * m;
-    out[((size_t)bi * c + ci) * n + pt] = sum3(w0, row[i0], w1, row[i1], w2, row[i2], cm);
+  const int nc = min(IC_CH, c - c0);
+  float p0[IC_CH], p1[IC_CH], p2[IC_CH];              // every gather of the IC_CH channels in flight before the first store
+#pragma unroll
+  for (int cc = 0; cc < IC_CH; ++cc) {
+    const float* row = points + ((size_t)bi * c + c0 + (cc < nc ? cc : 0)) * m;
+    p0[cc] = row[i0]; p1[cc] = row[i1]; p2[cc] = row[i2];
   }
+#pragma unroll
+  for (int cc = 0; cc < IC_CH; ++cc)
+    if (cc < nc) out[((size_t)bi * c + c0 + cc) * n + pt] = sum3<CM>(w0, p0[cc], w1, p1[cc], w2, p2[cc]);
 }
 
+// gradient: grad_points[b][c][idx[b][i][k]] += grad_out[b][c][i] * weight[b][i][k].  Like the grouping gradient: `cb` channel rows of one
+// cloud accumulate in LDS ([cb][m] floats, LDS atomics; a point's three indices and weights are loaded once for the cb channels) and are
+// added to grad_points by coalesced read-modify-writes; the global-atomic form stays for known clouds that do not fit.
+template <int CB>
+__global__ __launch_bounds__(256) void three_interpolate_grad_lds_kernel(int c, int n, int m, const float* __restrict__ grad_out,
+                                                                         const int32_t* __restrict__ idx, const float* __restrict__ weight,
+                                                                         float* __restrict__ grad_points) {
+  extern __shared__ __attribute__((aligned(16))) float s_acc[];   // [CB][m]
+  const int bi = blockIdx.y, c0 = blockIdx.x * CB;
+  const int nc = min(CB, c - c0);
+  for (int i = threadIdx.x; i < nc * m; i += 256) s_acc[i] = 0.f;
+  __syncthreads();
+  const float* go = grad_out + ((size_t)bi * c + c0) * n;
+  for (int pt = threadIdx.x; pt < n; pt += 256) {
+    const int32_t* ip = idx + ((size_t)bi * n + pt) * 3;
+    const float* wp = weight + ((size_t)bi * n + pt) * 3;
+    const int i0 = ip[0], i1 = ip[1], i2 = ip[2];
+    const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+    float g[CB];                                    // all loads of the step in flight before the first LDS atomic
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) g[cc] = cc < nc ? go[(size_t)cc * n + pt] : 0.f;
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc)
+      if (cc < nc) {
+        unsafeAtomicAdd(&s_acc[cc * m + i0], g[cc] * w0);
+        unsafeAtomicAdd(&s_acc[cc * m + i1], g[cc] * w1);
+        unsafeAtomicAdd(&s_acc[cc * m + i2], g[cc] * w2);
+      }
+  }
+  __syncthreads();
+  float* gp = grad_points + ((size_t)bi * c + c0) * m;
+  const int len = nc * m;
+  for (int i0 = threadIdx.x; i0 < len; i0 += 256 * 4) {
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = i0 + q * 256 < len ? gp[i0 + q * 256] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (i0 + q * 256 < len) gp[i0 + q * 256] = v[q] + s_acc[i0 + q * 256];
+  }
+}
 __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(int c, int n, int m, const float* __restrict__ grad_out,
                                                                      const int32_t* __restrict__ idx,
                                                                      const float* __restrict__ weight,
@@ -305,6 +482,26 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(int c, int 
   }
 }
 
+// channel rows per workgroup of the LDS-accumulating gradient kernels: a power of two <= 16 such that the rows of `len` floats fit
+// 64 KB of LDS and the launch has on the order of a thousand workgroups (b * c rows in all); 0: one row does not fit -> global atomics
+inline int lds_rows(int len, int b, int c) {
+  const int fit = 16384 / (len > 0 ? len : 1);
+  if (fit < 1) return 0;
+  const long long want = ((long long)b * c + 1023) / 1024;
+  int cb = 1;
+  while (cb * 2 <= 16 && cb * 2 <= fit && cb * 2 <= want) cb *= 2;
+  return cb;
+}
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+// launch KERNEL<..., CM> for the process-wide contraction mode
+#define U3D_PO_LAUNCH_CM(KERNEL, ...)                                                                 \
+  do {                                                                                                \
+    if (g_contraction == U3D_PO_FMA_LLVM) hipLaunchKernelGGL((KERNEL<U3D_PO_FMA_LLVM>), __VA_ARGS__);  \
+    else if (g_contraction == U3D_PO_FMA_CHAIN) hipLaunchKernelGGL((KERNEL<U3D_PO_FMA_CHAIN>), __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<U3D_PO_NO_FMA>), __VA_ARGS__);                                    \
+  } while (0)
+
 }  // namespace
 
 extern "C" {
@@ -320,19 +517,27 @@ int u3d_furthest_point_sampling(int b, int n, int m, const float* points, float*
   }
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)n * 3 * sizeof(float);
-#define FPS(T, P) hipLaunchKernelGGL((fps_kernel<T, P>), dim3(b), dim3(T), lds, s, n, m, lg, g_contraction, points, idx)
-  // small clouds: 4 waves keep the per-sample dependency chain short; larger ones spread over 16 waves
+#define FPS_CM(T, P, CM) hipLaunchKernelGGL((fps_kernel<T, P, CM>), dim3(b), dim3(T), lds, s, n, m, lg, points, idx)
+#define FPS(T, P)                                                    \
+  do {                                                               \
+    if (g_contraction == U3D_PO_FMA_LLVM) FPS_CM(T, P, U3D_PO_FMA_LLVM);        \
+    else if (g_contraction == U3D_PO_FMA_CHAIN) FPS_CM(T, P, U3D_PO_FMA_CHAIN); \
+    else FPS_CM(T, P, U3D_PO_NO_FMA);                                \
+  } while (0)
+  // small clouds: U3D_FPS_SMALL_THREADS / 64 waves keep the per-selection chain short; larger ones spread over U3D_FPS_BIG_THREADS / 64
+  constexpr int ST = U3D_FPS_SMALL_THREADS, BT = U3D_FPS_BIG_THREADS;
   if (n <= 256) FPS(256, 1);
-  else if (n <= 512) FPS(256, 2);
-  else if (n <= 1024) FPS(256, 4);
-  else if (n <= 2048) FPS(1024, 2);
-  else if (n <= 4096) FPS(1024, 4);
-  else if (n <= 8192) FPS(1024, 8);
+  else if (n <= 512) FPS(ST, 512 / ST);
+  else if (n <= 1024) FPS(ST, 1024 / ST);
+  else if (n <= 2048) FPS(512, 4);                   // (8 waves measured 5 % ahead of 16 here, 9 % behind at 8192)
+  else if (n <= 4096) FPS(BT, 4096 / BT);
+  else if (n <= 8192) FPS(BT, 8192 / BT);
   else {
     if (!temp) return 1;
-    hipLaunchKernelGGL(fps_kernel_large, dim3(b), dim3(1024), 0, s, n, m, lg, g_contraction, points, temp, idx);
+    U3D_PO_LAUNCH_CM(fps_kernel_large, dim3(b), dim3(1024), 0, s, n, m, lg, points, temp, idx);
   }
 #undef FPS
+#undef FPS_CM
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -342,8 +547,8 @@ int u3d_ball_query(int b, int n, int m, float radius, int nsample, const float* 
   if (b == 0 || m == 0 || nsample == 0) return 0;
   if (!new_xyz || !xyz || !idx) return 1;
   const int total = b * m;
-  hipLaunchKernelGGL(ball_query_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, n, m, total, radius * radius,
-                     nsample, g_contraction, new_xyz, xyz, idx);
+  U3D_PO_LAUNCH_CM(ball_query_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, n, m, total, radius * radius, nsample,
+                   new_xyz, xyz, idx);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -351,9 +556,14 @@ int u3d_group_points(int b, int c, int n, int npoints, int nsample, const float*
                      void* stream) {
   if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0) return 1;
   if (b == 0 || c == 0 || npoints * nsample == 0) return 0;
+  if (b > 65535 || c > 65535) return 1;
   if (!points || !idx || !out) return 1;
-  hipLaunchKernelGGL(group_points_kernel, dim3((npoints * nsample + 255) / 256, c, b), dim3(256), 0, (hipStream_t)stream, c, n,
-                     npoints, nsample, points, idx, out);
+  const int total = npoints * nsample;
+  if (total % 4 == 0 && aligned16(idx) && aligned16(out))
+    hipLaunchKernelGGL(group_points_vec_kernel, dim3((total / 4 + 255) / 256, (c + GP_CH - 1) / GP_CH, b), dim3(256), 0, (hipStream_t)stream,
+                       c, n, total, points, idx, out);
+  else
+    hipLaunchKernelGGL(group_points_kernel, dim3((total + 255) / 256, c, b), dim3(256), 0, (hipStream_t)stream, c, n, total, points, idx, out);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -361,9 +571,21 @@ int u3d_group_points_grad(int b, int c, int n, int npoints, int nsample, const f
                           float* grad_points, void* stream) {
   if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0) return 1;
   if (b == 0 || c == 0 || npoints * nsample == 0) return 0;
+  if (b > 65535 || c > 65535) return 1;
   if (!grad_out || !idx || !grad_points) return 1;
-  hipLaunchKernelGGL(group_points_grad_kernel, dim3((npoints * nsample + 255) / 256, c, b), dim3(256), 0, (hipStream_t)stream,
-                     c, n, npoints, nsample, grad_out, idx, grad_points);
+  const int total = npoints * nsample;
+  const int cb = lds_rows(n, b, c);
+#define GG(CB) hipLaunchKernelGGL((group_points_grad_lds_kernel<CB>), dim3((c + CB - 1) / CB, b), dim3(256), sizeof(float) * (size_t)CB * n, \
+                                  (hipStream_t)stream, c, n, total, grad_out, idx, grad_points)
+  if (cb == 16) GG(16);
+  else if (cb == 8) GG(8);
+  else if (cb == 4) GG(4);
+  else if (cb == 2) GG(2);
+  else if (cb == 1) GG(1);
+#undef GG
+  else
+    hipLaunchKernelGGL(group_points_grad_kernel, dim3((total + 255) / 256, c, b), dim3(256), 0, (hipStream_t)stream, c, n, total, grad_out, idx,
+                       grad_points);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -382,8 +604,7 @@ int u3d_three_nn(int b, int n, int m, const float* unknown, const float* known, 
   if (b == 0 || n == 0) return 0;
   if (b > 65535) return 1;
   if (!unknown || (m > 0 && !known) || !dist2 || !idx) return 1;
-  hipLaunchKernelGGL(three_nn_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS, b), dim3(NN_THREADS), 0, (hipStream_t)stream, n, m, g_contraction, unknown,
-                     known, dist2, idx);
+  U3D_PO_LAUNCH_CM(three_nn_kernel, dim3((n + NN_Q - 1) / NN_Q, b), dim3(NN_THREADS), 0, (hipStream_t)stream, n, m, unknown, known, dist2, idx);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -393,8 +614,8 @@ int u3d_three_interpolate(int b, int c, int m, int n, const float* points, const
   if (b == 0 || c == 0 || n == 0) return 0;
   if (b > 65535 || (c + IC_CH - 1) / IC_CH > 65535) return 1;
   if (!points || !idx || !weight || !out) return 1;
-  hipLaunchKernelGGL(three_interpolate_kernel, dim3((n + 255) / 256, (c + IC_CH - 1) / IC_CH, b), dim3(256), 0, (hipStream_t)stream, c, m,
-                     n, g_contraction, points, idx, weight, out);
+  U3D_PO_LAUNCH_CM(three_interpolate_kernel, dim3((n + 255) / 256, (c + IC_CH - 1) / IC_CH, b), dim3(256), 0, (hipStream_t)stream, c, m, n, points,
+                   idx, weight, out);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -404,8 +625,18 @@ int u3d_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out
   if (b == 0 || c == 0 || n == 0) return 0;
   if (b > 65535 || (c + IC_CH - 1) / IC_CH > 65535) return 1;
   if (!grad_out || !idx || !weight || !grad_points) return 1;
-  hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3((n + 255) / 256, (c + IC_CH - 1) / IC_CH, b), dim3(256), 0, (hipStream_t)stream,
-                     c, n, m, grad_out, idx, weight, grad_points);
+  const int cb = m > 0 ? lds_rows(m, b, c) : 0;
+#define IG(CB) hipLaunchKernelGGL((three_interpolate_grad_lds_kernel<CB>), dim3((c + CB - 1) / CB, b), dim3(256), sizeof(float) * (size_t)CB * m, \
+                                  (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points)
+  if (cb == 16) IG(16);
+  else if (cb == 8) IG(8);
+  else if (cb == 4) IG(4);
+  else if (cb == 2) IG(2);
+  else if (cb == 1) IG(1);
+#undef IG
+  else
+    hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3((n + 255) / 256, (c + IC_CH - 1) / IC_CH, b), dim3(256), 0, (hipStream_t)stream,
+                       c, n, m, grad_out, idx, weight, grad_points);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from . import _lib
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunipre3d_fusion.so")
+LIB_PATH = os.path.join(_lib.LIB_DIR, "libunipre3d_fusion.so")   # (U3D_LIB_DIRNAME: experiment builds, see _lib.py)
 EXPORTS = ("u3d_zbuffer_fusion_forward", "u3d_zbuffer_fusion_backward")
 _fu = None
 

@@ -27,7 +27,9 @@ from typing import Iterable
 
 import torch
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunipre3d_gradclip.so")
+from . import _lib
+
+LIB_PATH = os.path.join(_lib.LIB_DIR, "libunipre3d_gradclip.so")   # (U3D_LIB_DIRNAME: experiment builds, see _lib.py)
 EXPORTS = ("u3d_gradclip_stats", "u3d_gradclip_finalize", "u3d_gradclip_scale")
 GC_CHUNK = 65536
 _gc = None

@@ -14,7 +14,7 @@ from torch.autograd import Function
 
 from . import _lib
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunipre3d_pointops.so")
+LIB_PATH = os.path.join(_lib.LIB_DIR, "libunipre3d_pointops.so")   # (U3D_LIB_DIRNAME: experiment builds, see _lib.py)
 EXPORTS = ("u3d_furthest_point_sampling", "u3d_ball_query", "u3d_group_points", "u3d_group_points_grad",
            "u3d_gather_points", "u3d_gather_points_grad", "u3d_three_nn", "u3d_three_interpolate", "u3d_three_interpolate_grad",
            "u3d_pointops_set_contraction", "u3d_pointops_get_contraction")
