@@ -128,6 +128,8 @@ struct TileLds {   // wave-private; 2560 B of staged entries + 2560 B of gradien
   float2* P2;          // [64] b, pos (bits)
   float* D;            // [64] 1/depth (only the kernels that carry inverse depth)
   float (*acc)[10];    // [64] per slot: mx, my, mxx, mxy, myy, m0, r, g, b, d   (backward only)
+  float* S;            // [64], stride sstride: exp2(2 a'), the step ratio of the forward-differenced exponent (alpha_run).  The kernels
+  int sstride;         // without depth gradients keep it in the unused tenth float of the gradient rows: the wave stays at 5 KB of LDS
 };
 struct TileGeom {
   const uint32_t* sorted_id; const uint2* sorted_rect; const float2* xy; const float4* conic_op; const float4* rgbd;
@@ -149,7 +151,9 @@ struct TileGeom {
 //   * the staged quadratic form is negative semi-definite with margin, a', c' <= 0 and b'^2 <= 4 a' c' (1 - 1e-5): the computed
 //     pw = fma(fma(a', dx, b' dy), dx, (c' dy) dy) differs from the exact form by at most 4 * 2^-24 (|a'| dx^2 + |c'| dy^2),
 //     while the exact form is <= -(1e-5 / 2) (|a'| dx^2 + |c'| dy^2): the `pw > 0 -> skip` test can never fire (the pixel
-//     centre is finite; NaN alphas still fail the alpha >= 1/255 test).
+//     centre is finite; NaN alphas still fail the alpha >= 1/255 test);
+//   * a' >= -2.5 (conic xx <= 3.47: every covariance that went through the +0.3 low-pass has xx <= 3.34), which bounds how fast the
+//     exponent can fall along a lane's 4-pixel run -- what alpha_run needs.
 // Any entry outside these bounds (opacity above 0.98, a nearly singular or non-finite conic) sends the whole batch through the
 // loops that carry both tests, so results are identical either way.
 template <bool DEPTH>
@@ -169,12 +173,33 @@ __device__ __forceinline__ lanemask_t tile_stage(const TileLds& L, const TileGeo
     L.P1[o] = make_float4(c1, co.w, cd.x, cd.y);
     L.P2[o] = make_float2(cd.z, __uint_as_float(s + 1u));
     if (DEPTH) L.D[o] = 1.0f / cd.w;
-    ok = a1 <= 0.f && c1 <= 0.f && b1 * b1 <= (4.f * (1.f - 1e-5f)) * (a1 * c1) && co.w <= 0.98f && fabsf(m.x) < 1e30f && fabsf(m.y) < 1e30f;
+    L.S[o * L.sstride] = __builtin_amdgcn_exp2f(a1 + a1);
+    ok = a1 <= 0.f && a1 >= -2.5f && c1 <= 0.f && b1 * b1 <= (4.f * (1.f - 1e-5f)) * (a1 * c1) && co.w <= 0.98f && fabsf(m.x) < 1e30f && fabsf(m.y) < 1e30f;
   }
   plain = __ballot(!ok) == 0ull;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   return bal;
+}
+
+// PLAIN batches: opacity * exp2(pw) of the lane's four pixels with TWO transcendentals instead of four (round 5).  The lane's pixels are
+// dx0, dx0 - 1, dx0 - 2, dx0 - 3 and pw is quadratic in dx, so  pw(dx - 1) - pw(dx) = a'(1 - 2 dx) - b' dy  is linear and its step is the
+// constant 2 a':   alpha_0 = o exp2(pw_0),  r_0 = exp2(a'(1 - 2 dx0) - b' dy),  alpha_{k+1} = alpha_k r_k,  r_{k+1} = r_k s,  s = exp2(2 a')
+// staged once per entry (tile_stage).  11 multiply-add class instructions + 2 v_exp_f32 per lane and entry against 16 + 4.
+// Range: with a' >= -2.5 and the form negative semi-definite, sqrt(-pw) is a seminorm and the run spans sqrt(-pw(3, 0)) <= 4.75, so a
+// pixel that matters (o exp2(pw) >= 1/255, -pw <= 8) keeps every pw of its run above -57.3: nothing underflows before it; runs far from
+// the splat give 0 * inf = NaN at worst, which fails the alpha >= 1/255 test like the zero it stands for.
+__device__ __forceinline__ void alpha_run(float ax, float a1, float bdy, float cdy2, float op, float s2, float px0, float (&araw)[4]) {
+  const float dx0 = ax - px0;
+  const float pw0 = fmaf(fmaf(a1, dx0, bdy), dx0, cdy2);
+  const float dl = fmaf(a1, fmaf(-2.f, dx0, 1.f), -bdy);
+  float r = __builtin_amdgcn_exp2f(dl);
+  araw[0] = op * __builtin_amdgcn_exp2f(pw0);
+  araw[1] = araw[0] * r;
+  r *= s2;
+  araw[2] = araw[1] * r;
+  r *= s2;
+  araw[3] = araw[2] * r;
 }
 
 struct TileFwd {
@@ -217,11 +242,17 @@ __device__ __forceinline__ bool tile_forward(const TileLds& L, const TileGeom& G
       const float dy = A.y - pyf;
       const float bdy = A.w * dy, cdy2 = (Q.x * dy) * dy;
       lanemask_t contrib = 0ull, stopped = 0ull, m_stop[4];
+      float ar[4];
+      if (PLAIN) alpha_run(A.x, A.z, bdy, cdy2, Q.y, L.S[j * L.sstride], pxf[0], ar);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {   // one basic block: the four pixels' dependency chains interleave
-        const float dx = A.x - pxf[k];
-        const float pw = fmaf(fmaf(A.z, dx, bdy), dx, cdy2);
-        const float araw = Q.y * __builtin_amdgcn_exp2f(pw);
+        float pw = 0.f;
+        if (!PLAIN) {
+          const float dx = A.x - pxf[k];
+          pw = fmaf(fmaf(A.z, dx, bdy), dx, cdy2);
+          ar[k] = Q.y * __builtin_amdgcn_exp2f(pw);
+        }
+        const float araw = ar[k];
         const float alpha = PLAIN ? araw : min_099(araw);
         const lanemask_t m_ok = PLAIN ? __builtin_amdgcn_fcmpf(alpha, amin[k], U3D_FCMP_OGE)
                                       : __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE) & __builtin_amdgcn_fcmpf(alpha, amin[k], U3D_FCMP_OGE);
@@ -307,13 +338,18 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
       const uint32_t pos = __float_as_uint(R.y);
       const float dy = A.y - pyf;
       const float bdy = A.w * dy, cdy2 = (Q.x * dy) * dy;
-      float dx[4], ae[4];
+      float dx[4], ae[4], ar[4];
       lanemask_t any = 0ull;
+      if (PLAIN) alpha_run(A.x, A.z, bdy, cdy2, Q.y, L.S[j * L.sstride], pxf[0], ar);   // the forward's own values, bit for bit
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         dx[k] = A.x - pxf[k];
-        const float pw = fmaf(fmaf(A.z, dx[k], bdy), dx[k], cdy2);
-        const float araw = Q.y * __builtin_amdgcn_exp2f(pw);   // opacity * G (alpha before the 0.99 clamp)
+        float pw = 0.f;
+        if (!PLAIN) {
+          pw = fmaf(fmaf(A.z, dx[k], bdy), dx[k], cdy2);
+          ar[k] = Q.y * __builtin_amdgcn_exp2f(pw);
+        }
+        const float araw = ar[k];   // opacity * G (alpha before the 0.99 clamp)
         const lanemask_t m_a = (PLAIN ? ~0ull : __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE)) & __builtin_amdgcn_fcmpf(araw, ALPHA_MIN, U3D_FCMP_OGE);
         ae[k] = mask_combine_sel0<false>(m_a, __builtin_amdgcn_uicmp(pos, lim[k], U3D_ICMP_ULT), any, araw);
       }
@@ -558,8 +594,9 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
   __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ float sD[TILE_WAVES][DEPTH ? U3D_WAVE : 1];
+  __shared__ float sS[TILE_WAVES][U3D_WAVE];
   U3D_TILE_PROLOGUE(TILE_WAVES);
-  const TileLds L{sP0[wave], sP1[wave], sP2[wave], sD[wave], nullptr};
+  const TileLds L{sP0[wave], sP1[wave], sP2[wave], sD[wave], nullptr, sS[wave], 1};
   TileFwd F;
   const uint32_t nv = n_vis[view];
   const bool plain = tile_forward<DEPTH, true>(L, G, lane, nv, pyf, pxf, inside, F);
@@ -608,8 +645,9 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ float sD[TILE_WAVES][HAS_INVD ? U3D_WAVE : 1];
   __shared__ __attribute__((aligned(8))) float sAcc[TILE_WAVES][U3D_WAVE][10];
+  __shared__ float sS[TILE_WAVES][HAS_INVD ? U3D_WAVE : 1];   // (with depth gradients the rows' tenth float is in use)
   U3D_TILE_PROLOGUE(TILE_WAVES);
-  const TileLds L{sP0[wave], sP1[wave], sP2[wave], sD[wave], sAcc[wave]};
+  const TileLds L{sP0[wave], sP1[wave], sP2[wave], sD[wave], sAcc[wave], HAS_INVD ? sS[wave] : &sAcc[wave][0][9], HAS_INVD ? 1 : 10};
 #pragma unroll
   for (int k = 0; k < 5; ++k) reinterpret_cast<float2*>(&sAcc[wave][lane][0])[k] = make_float2(0.f, 0.f);
 
@@ -682,7 +720,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ __attribute__((aligned(8))) float sAcc[TILE_WAVES][U3D_WAVE][10];
   U3D_TILE_PROLOGUE(TILE_WAVES);
-  const TileLds L{sP0[wave], sP1[wave], sP2[wave], nullptr, sAcc[wave]};
+  const TileLds L{sP0[wave], sP1[wave], sP2[wave], nullptr, sAcc[wave], &sAcc[wave][0][9], 10};
 #pragma unroll
   for (int k = 0; k < 5; ++k) reinterpret_cast<float2*>(&sAcc[wave][lane][0])[k] = make_float2(0.f, 0.f);
   TileFwd F;
