@@ -58,8 +58,11 @@ extern "C" {
                                     caller hands the forward half the gradient buffer `d_head_out` it will pass to the backward half.
                                     The forward half zero-fills it (extra workgroups of the gradient reduction, off the critical path)
                                     and records which Gaussians received a gradient; the backward half then runs the chain rule over
-                                    those few thousand instead of visiting every one of the scene's 10^5 Gaussians.  Set the flag in
-                                    BOTH halves' descriptors or in neither */
+                                    those few thousand instead of visiting every one of the scene's 10^5 Gaussians.  Meant to be set in
+                                    both halves' descriptors or in neither; a mismatch costs speed, not correctness: a forward half
+                                    without the flag marks the list as not built and a backward half with it then visits every Gaussian,
+                                    a backward half without it always does.  `d_head_out` is validated (non-null, 16-byte aligned) with
+                                    the other arguments, before anything is enqueued */
 
 #define U3D_OK 0
 #define U3D_ERR_INVALID_ARGUMENT 1

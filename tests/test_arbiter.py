@@ -70,13 +70,14 @@ def test_the_one_parity_rule():
     n0 = len(arbiter.GAP_PASSES)
     arbiter.assert_parity(mk(5e-5), mk(2e-5), o64, "within tol")
     assert len(arbiter.GAP_PASSES) == n0
-    arbiter.assert_parity(mk(3.6e-3), mk(3.6e-3 + 1e-6), o64, "equals the fp32 restatement, far from fp64")      # uncapped: e32 <= tol
+    arbiter.assert_parity(mk(3.6e-3), mk(3.6e-3 + 1e-6), o64, "equals the fp32 restatement, far from fp64")      # e32 <= tol, under 100 x tol
     arbiter.assert_parity(mk(5e-4), mk(3e-4), o64, "capped gap")                                                  # e32 = 2e-4 > tol, under the cap
     assert len(arbiter.GAP_PASSES) == n0 + 2 and "[= fp32 restatement]" in arbiter.GAP_PASSES[n0][0] and "[capped gap]" in arbiter.GAP_PASSES[n0 + 1][0]
     del arbiter.GAP_PASSES[n0:]
     for x, o32 in ((mk(3e-3), mk(2e-3)),        # beyond the cap and not equal to the fp32 restatement
                    (mk(5e-4), mk(2e-4)),        # farther from the arbiter than 2 x the restatement's own gap
-                   (mk(2e-4), mk(1e-6))):       # the restatement resolves the quantity: no allowance
+                   (mk(2e-4), mk(1e-6)),        # the restatement resolves the quantity: no allowance
+                   (mk(2e-2), mk(2e-2 + 1e-6))):  # equal to the fp32 restatement but 200 x tol from the arbiter: beyond the absolute ceiling
         with pytest.raises(AssertionError):
             arbiter.assert_parity(x, o32, o64, "must fail")
     assert len(arbiter.GAP_PASSES) == n0

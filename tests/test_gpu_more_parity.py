@@ -188,6 +188,85 @@ def test_sparse_backward_flag_equals_the_dense_chain_rule(P, level):
         assert set(rows.tolist()) <= set(ids.tolist())
 
 
+@pytest.mark.parametrize("fwd_sparse,bwd_sparse", [(False, True), (True, False)])
+def test_sparse_flag_in_one_half_only_still_gives_the_dense_gradient(fwd_sparse, bwd_sparse):
+    """U3D_FLAG_SPARSE_BWD set in ONE half of the step.  Forward without / backward with used to return U3D_OK and an
+    uninitialised gradient (no list was built); now the forward half leaves the count at U3D_TOUCHED_NOT_LISTED and the backward half walks
+    its grid densely.  Forward with / backward without was always fine (the dense form writes every row).  Both from a garbage-filled buffer."""
+    import ctypes
+    import math
+    from unipre3d_amd import _lib, synthetic
+    from unipre3d_amd.rasterizer import _Plan
+    dev = torch.device("cuda:0")
+    H, W, P, level = 96, 128, 5000, "scene"
+    bd = synthetic.make_batch(2, P, 3, H, W, level=level, seed=29).to(dev)
+    l0, g0, _, _ = _step_via_cabi(bd, H, W, level, _lib.FLAG_ANTIALIASING, 7.0)
+    B, C, _ = bd.raw.shape
+    V = bd.world_view.shape[1]
+    NV = B * V
+    t = math.tan(bd.fov_deg * math.pi / 360)
+    fl = lambda sp: _lib.FLAG_ANTIALIASING | (_lib.FLAG_SPARSE_BWD if sp else 0)
+    pf, pb = _Plan(B, V, P, H, W, t, t, 1.0, 1, 4, fl(fwd_sparse)), _Plan(B, V, P, H, W, t, t, 1.0, 1, 4, fl(bwd_sparse))
+    hd = _lib.HeadDesc(2, C, bd.offset_scale, 0)
+    ld = _lib.LossDesc(_lib.LOSS_KINDS["l2"], 4.0, 1.0)
+    head_out = bd.raw.permute(0, 2, 1).contiguous()
+    u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+    geom, binning, fused_s = u8(pf.sizes.geom_bytes), u8(pf.sizes.binning_bytes), u8(pf.sizes.fused_bytes)
+    bwd = torch.zeros(pf.sizes.backward_bytes, dtype=torch.uint8, device=dev)
+    radii = torch.zeros(NV, P, dtype=torch.int32, device=dev)
+    loss = torch.zeros((), device=dev)
+    d_head = torch.full_like(head_out, -5.0)
+    p, c = _lib.ptr, lambda x: x.contiguous()
+    cams = (p(c(bd.world_view).reshape(NV, 16)), p(c(bd.full_proj).reshape(NV, 16)), p(c(bd.camera_center).reshape(NV, 3)))
+    strm = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lib = _lib.load()
+    _lib.check(lib.u3d_render_loss_step_forward(ctypes.byref(pf.desc), ctypes.byref(hd), ctypes.byref(ld), p(bd.bg), p(head_out), p(c(bd.center)), *cams,
+                                                p(c(bd.gt).reshape(NV, 3, H, W)), p(None), p(radii), p(loss), p(geom), p(binning), p(fused_s), p(bwd),
+                                                p(d_head), strm), "u3d_render_loss_step_forward")
+    _lib.check(lib.u3d_render_loss_step_backward(ctypes.byref(pb.desc), ctypes.byref(hd), p(head_out), p(c(bd.center)), *cams, p(radii), p(None),
+                                                 p(geom), p(binning), p(fused_s), p(bwd), p(d_head), strm), "u3d_render_loss_step_backward")
+    torch.cuda.synchronize()
+    assert loss.item() == l0
+    assert torch.equal(g0 == 0, d_head == 0)
+    assert rel_l2(d_head.cpu().numpy(), g0.cpu().numpy()) < 1e-6
+    # a misaligned / missing gradient buffer with the flag is refused BEFORE anything is enqueued (ADVICE r04): the accumulators stay zero
+    if fwd_sparse:
+        bwd.zero_()
+        rc = lib.u3d_render_loss_step_forward(ctypes.byref(pf.desc), ctypes.byref(hd), ctypes.byref(ld), p(bd.bg), p(head_out), p(c(bd.center)), *cams,
+                                              p(c(bd.gt).reshape(NV, 3, H, W)), p(None), p(radii), p(loss), p(geom), p(binning), p(fused_s), p(bwd),
+                                              p(None), strm)
+        torch.cuda.synchronize()
+        assert rc == 1 and not bool(bwd.any())
+
+
+def test_fused_step_under_no_grad_and_inference_mode_then_training():
+    """(i) an eval pass under torch.inference_mode() BEFORE training must not poison the cached viewspace sink of
+    render_predicted; (ii) the scene-level fused step under no_grad allocates no gradient buffer and a later training step is unaffected."""
+    import types
+    from unipre3d_amd import fused, renderer, synthetic
+    dev = torch.device("cuda:0")
+    H, W, P = 64, 64, 777
+    bd = synthetic.make_batch(1, P, 1, H, W, level="object", seed=3).to(dev)
+    g = synthetic.gaussians_from_batch(bd)
+    cfg = types.SimpleNamespace(data=types.SimpleNamespace(fov=bd.fov_deg, training_resolution=H), model=types.SimpleNamespace(max_sh_degree=1))
+    pc = {k: v[0].contiguous() for k, v in g.items()}
+    with torch.inference_mode():
+        e = renderer.render_predicted(pc, bd.world_view[0, 0], bd.full_proj[0, 0], bd.camera_center[0, 0], bd.bg, cfg)["render"]
+    pc_t = {k: v.clone().requires_grad_(True) for k, v in pc.items()}
+    out = renderer.render_predicted(pc_t, bd.world_view[0, 0], bd.full_proj[0, 0], bd.camera_center[0, 0], bd.bg, cfg)
+    out["render"].sum().backward()
+    assert torch.equal(out["render"].detach(), e) and pc_t["xyz"].grad is not None and out["viewspace_points"].grad is not None
+    bs = synthetic.make_batch(1, 5000, 2, H, W, level="scene", seed=4).to(dev)
+    h = bs.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+    args = (bs.center, bs.world_view, bs.full_proj, bs.camera_center, bs.gt, bs.bg, bs.fov_deg, H, W)
+    kw = dict(level="scene", offset_scale=bs.offset_scale, loss_kind="l2", return_images=False)
+    with torch.no_grad():
+        l_eval, _, _ = fused.render_loss_fused(h, *args, **kw)
+    l_train, _, _ = fused.render_loss_fused(h, *args, **kw)
+    l_train.backward()
+    assert l_eval.item() == l_train.item() and h.grad is not None and bool(torch.isfinite(h.grad).all()) and float(h.grad.abs().sum()) > 0
+
+
 def test_render_view_entry_points_equal_the_operator_entry_points(oracle_mod):
     """u3d_render_view_forward / _backward (ABI 5: features_dc / features_rest through two pointers, visibility from the projection
     kernel, no inverse-depth plane) against u3d_rasterize_forward / _backward on the concatenated SH tensor, through ctypes, for a

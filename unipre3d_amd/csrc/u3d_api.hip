@@ -457,6 +457,10 @@ int u3d_render_loss_step_forward(const u3d_raster_desc* desc, const u3d_head_des
   if (!bg || !head_out || !center || !viewmatrix || !projmatrix || !campos || !gt || !radii || !loss_out || !geom || !binning ||
       !fused || !backward_scratch)
     return U3D_ERR_INVALID_ARGUMENT;
+  // U3D_FLAG_SPARSE_BWD: the gradient buffer is zero-filled beside the gradient reduction and the touched Gaussians are listed
+  // (checked with the other arguments: nothing is in flight yet when a bad pointer is refused)
+  const bool sparse = u3d_sparse_bwd(d, head->mode);
+  if (sparse && (!d_head_out || (reinterpret_cast<uintptr_t>(d_head_out) & 15u) != 0u)) return U3D_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
   if ((rc = validate_offsets(d, geom, s)) != U3D_OK) return rc;
   U3DBuffers b{};
@@ -482,9 +486,6 @@ int u3d_render_loss_step_forward(const u3d_raster_desc* desc, const u3d_head_des
     u3d_launch_depth_sort(d, b, radii, s);
   }
   const U3DLoss L = make_loss(d, *loss, gt, f.partial, nullptr);
-  // U3D_FLAG_SPARSE_BWD: the gradient buffer is zero-filled beside the gradient reduction and the touched Gaussians are listed
-  const bool sparse = u3d_sparse_bwd(d, head->mode);
-  if (sparse && (!d_head_out || (reinterpret_cast<uintptr_t>(d_head_out) & 15u) != 0u)) return U3D_ERR_INVALID_ARGUMENT;
   {
     ProfScope ps(5, s);
     u3d_launch_render_fb(d, b, bg, out_color, L, acc, part, loss_out, s, sparse ? d_head_out : nullptr,

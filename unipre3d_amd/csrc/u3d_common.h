@@ -254,6 +254,7 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
                                uint8_t* visible = nullptr);   // visible[pair] = radius > 0 (`visibility_filter`, gaussian_renderer/__init__.py:103)
 // (preprocess_bwd triages by b.touched_words when d.P > U3D_LDS_SORT_MAX; the reduction kernels set the bits in that case)
 static inline bool u3d_uses_touched_words(const u3d_raster_desc& d) { return d.P > U3D_LDS_SORT_MAX; }
+#define U3D_TOUCHED_NOT_LISTED 0xFFFFFFFFu   // value of the touched count after a forward half that built no list
 // large-P sort: the tile kernels read a sorted entry's rectangle through sorted_id (b.rect) instead of a sorted copy (b.sorted_rect)
 static inline int u3d_rect_indirect(const u3d_raster_desc& d) { return d.P > U3D_LDS_SORT_MAX ? 1 : 0; }
 void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, const U3DSource& src, const float* viewmatrix,

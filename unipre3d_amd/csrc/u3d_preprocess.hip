@@ -131,8 +131,9 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     float4* __restrict__ rgbd, uint2* __restrict__ rect, uint32_t* __restrict__ clamped,
     uint32_t* __restrict__ num_rendered, double* __restrict__ acc_zero, size_t NG, uint32_t* __restrict__ sorted_id,
     uint2* __restrict__ sorted_rect, uint32_t* __restrict__ n_vis, uint32_t* __restrict__ msd_total, int msd_bins,
-    uint32_t* __restrict__ touched_words, uint8_t* __restrict__ visible, uint32_t* __restrict__ touched_count) {
-  if (touched_count && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *touched_count = 0u;   // (the touched list restarts)
+    uint32_t* __restrict__ touched_words, uint8_t* __restrict__ visible, uint32_t* __restrict__ touched_count, uint32_t touched_count_init) {
+  // (the touched list restarts; U3D_TOUCHED_NOT_LISTED when this step does not build one, so that a sparse backward half can tell)
+  if (touched_count && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *touched_count = touched_count_init;
   // (msd_total != null: P > 4096; the depth sort that follows partitions by depth bucket with one global atomic per (workgroup,
   // bucket) on these per-view totals -- the first workgroup of every (set, view slice) clears them here instead of a memset node)
   if (msd_total && blockIdx.x == 0) {
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped, const double* acc, double* acc_reset,
     U3DGradSink sink, const float* __restrict__ gscale, const uint32_t* __restrict__ touched_words,
-    const uint2* __restrict__ sparse_list, const uint32_t* __restrict__ sparse_count) {
+    const uint2* __restrict__ sparse_list_in, const uint32_t* __restrict__ sparse_count) {
 #pragma clang fp contract(fast)
   // gscale: device scalar dL/dloss of the fused step (autograd's grad_output) or null (= 1).  Every output of this kernel -- and the
   // column dot products quat_fixup finishes -- is linear in the accumulators, so scaling them as they are read IS the d_head * g
@@ -357,11 +358,23 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
   // sparse mode (U3D_FLAG_SPARSE_BWD, scene level): the quad's Gaussian comes from the touched list the gradient reduction
   // appended to -- (set, index) in arrival order; the rows of every other Gaussian were zero-filled by the forward half and a
   // workgroup beyond the end of the list leaves at once
-  int item = blockIdx.y, i = blockIdx.x * (U3D_BLOCK / 4) + (threadIdx.x >> 2);
+  // A forward half that ran WITHOUT U3D_FLAG_SPARSE_BWD leaves the count at U3D_TOUCHED_NOT_LISTED (and did not zero-fill): this launch then
+  // walks its grid -- sized n_items x ceil(P / 64) in sparse mode for exactly this -- as the dense form does (one flag in one half only
+  // used to return U3D_OK with an uninitialised gradient).
+  const uint2* sparse_list = sparse_list_in;
+  int item = blockIdx.y, bx = blockIdx.x;
+  if (sparse_list) {
+    const uint32_t n = *sparse_count;
+    if (n == U3D_TOUCHED_NOT_LISTED) {
+      const int bpi = (span.P + U3D_BLOCK / 4 - 1) / (U3D_BLOCK / 4);
+      item = bx / bpi; bx -= item * bpi;
+      sparse_list = nullptr;
+    } else if ((uint32_t)(bx * (U3D_BLOCK / 4)) >= n) return;
+  }
+  int i = bx * (U3D_BLOCK / 4) + (threadIdx.x >> 2);
   bool listed = true;
   if (sparse_list) {
     const uint32_t n = *sparse_count;
-    if ((uint32_t)(blockIdx.x * (U3D_BLOCK / 4)) >= n) return;
     listed = (uint32_t)i < n;
     const uint2 e = sparse_list[listed ? i : 0];
     item = (int)e.x; i = (int)e.y;
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
   // then only the waves that own a touched Gaussian compute anything; a row-by-row zero fill from each idle wave ran at ~1 TB/s
   const bool block_zero = !sparse_list && !lane_live && src.act != 0;
   if (block_zero) {
-    const int C = src.s_means, ib = blockIdx.x * (U3D_BLOCK / 4), rows = min(U3D_BLOCK / 4, P - ib);
+    const int C = src.s_means, ib = bx * (U3D_BLOCK / 4), rows = min(U3D_BLOCK / 4, P - ib);
     if (rows > 0) {
       float* o = sink.means + (gbase + ib) * C;
       const int n = rows * C;
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_bwd_kernel(
     if (src.act != 0) {
       if (!block_zero) {
         // fused mode: the gradient rows of the wave's 16 Gaussians are 16 * C consecutive floats of d(head output)
-        const int C = src.s_means, iw = blockIdx.x * (U3D_BLOCK / 4) + (threadIdx.x >> 6) * 16, n = min(16, P - iw) * C;
+        const int C = src.s_means, iw = bx * (U3D_BLOCK / 4) + (threadIdx.x >> 6) * 16, n = min(16, P - iw) * C;
         float* o = sink.means + (gbase + iw) * C;
         for (int e = threadIdx.x & 63; e < n; e += 64) o[e] = 0.f;
       }
@@ -831,7 +844,8 @@ void u3d_launch_preprocess_fwd(const u3d_raster_desc& d, const U3DBuffers& b, co
                      radii, b.depth, b.xy, b.conic_op, b.rgbd, b.rect, b.clamped, b.num_rendered, acc_zero, NG,               \
                      fuse_sort ? b.sorted_id : nullptr, b.sorted_rect, b.n_vis, d.P > U3D_LDS_SORT_MAX ? b.sort_hist : nullptr, u3d_msd_bins(d.P), \
                      u3d_uses_touched_words(d) ? b.touched_words : nullptr, visible,                                      \
-                     u3d_uses_touched_words(d) ? b.touched_count : nullptr)
+                     u3d_uses_touched_words(d) ? b.touched_count : nullptr,                                              \
+                     u3d_sparse_bwd(d, src.act) ? 0u : U3D_TOUCHED_NOT_LISTED)
   switch (D) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;
@@ -848,7 +862,9 @@ void u3d_launch_preprocess_bwd(const u3d_raster_desc& d, const U3DBuffers& b, co
   dim3 grid((d.P + U3D_BLOCK / 4 - 1) / (U3D_BLOCK / 4), d.n_items), block(U3D_BLOCK);
   // sparse: one linear grid over the touched list, sized for the worst case (every Gaussian touched); workgroups past the
   // device-side count leave at once
-  if (sparse) grid = dim3((unsigned)((u3d_total_P(d) + U3D_BLOCK / 4 - 1) / (U3D_BLOCK / 4)), 1);
+  // (n_items x ceil(P / 64) >= ceil(total_P / 64) blocks: also enough for the dense walk the kernel falls back to when the forward half
+  // did not list)
+  if (sparse) grid = dim3((unsigned)(grid.x * grid.y), 1);
   const int D = src.shs ? d.sh_degree : 0;
   const int flags = d.flags | (d.P > U3D_LDS_SORT_MAX ? U3D_FLAG_INTERNAL_TRIAGE : 0);   // scene level: most waves only write zeros
   const uint2* sl = sparse ? b.touched_list : nullptr;

@@ -22,6 +22,7 @@
 #ifndef U3D_BINDING_NO_SPARSE
 #define U3D_BINDING_NO_SPARSE 0   /* experiments: 1 = never ask for U3D_FLAG_SPARSE_BWD */
 #endif
+constexpr int64_t kSparseMinP = 4096;   // the library honours U3D_FLAG_SPARSE_BWD above its LDS-sort limit (U3D_LDS_SORT_MAX, u3d_common.h)
 
 namespace {
 
@@ -282,12 +283,14 @@ Tensor viewspace_sink(const Tensor& xyz) {
     std::lock_guard<std::mutex> lock(g_sink_mu);
     const std::pair<int, int64_t> key{(int)xyz.device().index(), xyz.numel()};
     auto it = g_sink->find(key);
-    if (it == g_sink->end()) {
+    if (it == g_sink->end() || it->second.is_inference()) {   // (an inference tensor can never become a requires_grad leaf: rebuilt)
       if (g_sink->size() >= 64) g_sink->clear();
-      it = g_sink->emplace(key, at::zeros({xyz.numel()}, xyz.options().dtype(at::kFloat))).first;
+      c10::InferenceMode normal(false);   // the first call may come from an eval pass under torch.inference_mode()
+      it = g_sink->insert_or_assign(key, at::zeros({xyz.numel()}, xyz.options().dtype(at::kFloat))).first;
     }
     z = it->second;
   }
+  c10::InferenceMode normal(false);
   Tensor leaf = z.view(xyz.sizes()).detach();
   leaf.set_requires_grad(true);
   return leaf;
@@ -432,7 +435,7 @@ struct RenderLossStepFn : public torch::autograd::Function<RenderLossStepFn> {
     u3d_raster_desc d{};
     d.n_items = (int32_t)B; d.views_per_item = (int32_t)V; d.P = (int32_t)P; d.image_height = (int32_t)H; d.image_width = (int32_t)W;
     d.tanfovx = d.tanfovy = (float)tanfov; d.scale_modifier = (float)scale_modifier; d.sh_degree = (int32_t)sh_degree;
-    d.sh_coeffs = (int32_t)K; d.flags = (int32_t)flags | (mode == 2 && !U3D_BINDING_NO_SPARSE ? U3D_FLAG_SPARSE_BWD : 0); d.total_P = (int32_t)total_P;
+    d.sh_coeffs = (int32_t)K; d.flags = (int32_t)flags; d.total_P = (int32_t)total_P;   // (U3D_FLAG_SPARSE_BWD: decided by render_loss_step below)
     d.item_offsets = ragged ? offsets.data_ptr<int32_t>() : nullptr;
     const Plan plan = plan_for(d);
     u3d_head_desc hd{(int32_t)mode, (int32_t)C, (float)offset_scale, isotropic ? 1 : 0};
@@ -559,9 +562,16 @@ std::tuple<Tensor, Tensor, Tensor> render_loss_step(const Tensor& head_out, cons
                                                     const c10::optional<Tensor>& item_offsets, int64_t max_P) {
   const c10::Device dev = head_out.device();
   const int64_t NV = view.numel() / 16;
+  // U3D_FLAG_SPARSE_BWD (gradient buffer allocated in forward, touched list) is asked for only where the library honours it AND a
+  // backward can follow: scene-level head, more Gaussians per set than the LDS sort takes, head_out on the tape with grad mode on.
+  // Decided here: inside Function::forward grad mode is always off.  Otherwise (eval / no_grad / small sets) the backward half
+  // allocates its buffer lazily as before and nothing is pinned from forward to backward.
+  const int64_t set_P = item_offsets.has_value() && item_offsets->defined() ? max_P : (head_out.dim() >= 2 ? head_out.size(-2) : 0);
+  const bool sparse = mode == 2 && !U3D_BINDING_NO_SPARSE && set_P > kSparseMinP && at::GradMode::is_enabled() && head_out.requires_grad();
   auto r = RenderLossStepFn::apply(f32c(head_out, dev), f32c(center, dev), f32c(view, dev).reshape({NV, 16}), f32c(proj, dev).reshape({NV, 16}),
                                    f32c(campos, dev).reshape({NV, 3}), f32c(gt, dev), f32c(bg, dev).reshape({3}), H, W, tanfov, mode, offset_scale,
-                                   sh_degree, loss_kind, non_bg_rate, bg_rate, scale_modifier, flags, want_color, isotropic, item_offsets, max_P);
+                                   sh_degree, loss_kind, non_bg_rate, bg_rate, scale_modifier,
+                                   (flags & ~(int64_t)U3D_FLAG_SPARSE_BWD) | (sparse ? (int64_t)U3D_FLAG_SPARSE_BWD : 0), want_color, isotropic, item_offsets, max_P);
   return {r[0], r[1], r[2]};
 }
 
