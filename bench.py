@@ -193,7 +193,7 @@ def consumed_roofline(dom, Rc, tiles, HW, NV, avg_ms):
     return per_inst, by_c, by_c / 1e9 / (avg_ms / 1e3)
 
 
-def other_config_region(name, compact, rank, dev, steps=30, warmup=5):
+def other_config_region(name, compact, rank, dev, steps=30, warmup=5, world=1):
     """The hot-only step (the contractual region's definition: activations -> batched render -> loss -> backward -> dL/d head_out,
     seeded by a plain loss.backward()) of ANOTHER BASELINE config, timed in the default driver run so that the scene-level figures
     (BASELINE configs[2..4]; `--compact`: SURVEY 8d's secondary regime) are driver-observed, not builder-printed.  ~1-2 s each."""
@@ -219,24 +219,31 @@ def other_config_region(name, compact, rank, dev, steps=30, warmup=5):
         torch.cuda.synchronize()
 
     def region(profile):
+        """`steps` steps between two host barriers; the MAX over ranks of the elapsed time (every rank runs its own B objects: weak scaling,
+        no collective inside -- the contractual region's bracket)."""
         for _ in range(warmup):
             hot()
         torch.cuda.synchronize()
+        dp.host_barrier()
         if profile:
             _lib.profile_begin(8 * (steps + 2), ("render_fb",), stride=2)
         t0 = time.perf_counter()
         for _ in range(steps):
             l = hot()
         torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+        dp.host_barrier()
+        el = dp.host_all_reduce_max(time.perf_counter() - t0)
         return el, (_lib.profile_end() if profile else None), l
 
     el, prof, l = region(True)
     reps = sorted(1e3 * region(False)[0] / steps for _ in range(3))
     NV, tiles = B * V, ((W + 15) // 16) * ((H + 15) // 16)
-    out = {"ms_per_step": 1e3 * el / steps, "views_s": NV * steps / el, "steps": steps, "warmup": warmup, "repeat_min_ms": reps[0],
+    out = {"ms_per_step": 1e3 * el / steps, "views_s": world * NV * steps / el, "n_gpus": world, "steps": steps, "warmup": warmup, "repeat_min_ms": reps[0],
            "repeat_median_ms": reps[1], "final_loss": float(l),
-           "workload": f"{name}{' compact' if compact else ''}: {level}-level, P={P}, {H}x{W}, B={B} x V={V} = {NV} renders/step, loss {loss_kind}"}
+           "workload": f"{name}{' compact' if compact else ''}: {level}-level, P={P}, {H}x{W}, B={B} x V={V} = {NV} renders/step"
+                       + (f" per rank x {world} ranks (max-over-ranks time)" if world > 1 else "") + f", loss {loss_kind}"}
+    if rank != 0:
+        return out
     ms, cnt = prof["render_fb"]
     if cnt:
         out["tile_kernel_ms"] = ms / cnt
@@ -1012,8 +1019,11 @@ def main():
                             "inverse-depth plane the reference's wrapper drops; same algorithmic bytes as above (SURVEY 8d prices 24 B per pixel)"}
         elif fwd_err:
             out["forward_rasterizer"] = {"error": fwd_err}
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline:
+            # (at N > 1 too: rank 0 times it while the other ranks wait at the host barrier below, so that every line the driver reads is complete)
             out["cpu_baseline"] = cpu_baseline(host_batch, H, W, a.cpu_seconds)
+    if world > 1:
+        dp.host_barrier()
 
     # The contractual line is complete at this point.  The secondary regions below use RCCL (DDP) at N > 1; if one of them
     # stalls, every rank's watchdog ends the process after the budget and rank 0 prints the line without them.
@@ -1122,14 +1132,21 @@ def main():
             extras["train_step_e2e_standin"] = e2e_region(a, batch, dev, world, rank, B, V, H, W, loss_kind, timed)
         except Exception as e:  # noqa: BLE001
             extras["train_step_e2e_standin"] = {"error": repr(e)[:300]}
-    if world == 1 and a.config == "C2" and not (a.compact or a.unfused or a.two_pass or a.hot_only or a.no_other_configs):
-        # the other BASELINE configs' hot-only steps in the driver's own run
+    if a.config == "C2" and not (a.compact or a.unfused or a.two_pass or a.hot_only or a.no_other_configs):
+        # the other BASELINE configs' hot-only steps in the driver's own run.  N = 1: all of them.  N > 1 (VERDICT r04
+        # item 4): the configs BASELINE.json assigns to that GPU count -- C3 (pointmlp shape: 4 GPUs; also reported at 2), C4 / C5 and their
+        # "+ fused pixel-Gaussians" forms at 8 -- every rank on its own per-GPU batch, max-over-ranks time, no collective.
+        every = (("C3", ("C3", False)), ("C4", ("C4", False)), ("C5", ("C5", False)), ("C2_compact", ("C2", True)),
+                 ("C4_fused", ("C4_fused", False)), ("C5_fused", ("C5_fused", False)))
+        chosen = every if world == 1 else tuple(e for e in every if e[0] in (("C3",) if world < 8 else ("C3", "C4", "C5", "C4_fused", "C5_fused")))
         oc = {}
-        for key, (cname, comp) in (("C3", ("C3", False)), ("C4", ("C4", False)), ("C5", ("C5", False)), ("C2_compact", ("C2", True))):
+        for key, (cname, comp) in chosen:
             try:
-                oc[key] = other_config_region(cname, comp, rank, dev)
+                oc[key] = other_config_region(cname, comp, rank, dev, world=world)
             except Exception as e:  # noqa: BLE001
                 oc[key] = {"error": repr(e)[:300]}
+                if world > 1:
+                    break          # (the ranks would no longer meet at the same barriers)
             torch.cuda.empty_cache()
         extras["other_configs"] = oc
 

@@ -39,9 +39,15 @@ def test_bench_line_single_gpu_small_config():
 
 
 def test_bench_self_launches_two_ranks():
-    out = _run(["--gpus", "2", "--config", "C1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+    out = _run(["--gpus", "2", "--config", "C1", "--steps", "4", "--warmup", "1", "--cpu-seconds", "1"],
                env={"U3D_BENCH_SHARE_GPU": "1", "U3D_BENCH_EXTRAS_BUDGET_S": "240"})
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["views_per_step"] == 16
+    # an N > 1 line is field for field as complete as the N = 1 line: roofline AND cpu_baseline (rank 0 times it
+    # while the other ranks wait at the host barrier), plus the rows N1 / N4a
+    for k in CONTRACT + ("cpu_baseline", "pointops", "fusion"):
+        assert k in out, k
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0 and out["roofline"]["frac"] > 0
+    assert "error" not in out["pointops"] and out["pointops"]["all_equal_oracle"] and out["fusion"]["forward"]["equals_oracle"]
     assert abs(out["value"] - 16 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"]
     e2e = out["train_step_e2e_standin"]
     assert "error" not in e2e, e2e
@@ -72,14 +78,20 @@ def test_bench_under_torch_distributed_run():
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C1", "--steps", "4", "--warmup", "1",
-           "--no-cpu-baseline", "--no-e2e"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--no-cpu-baseline", "--no-e2e", "--no-next-rows"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, U3D_BENCH_BACKEND="gloo"))
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and "error" not in out["train_step_with_head"]
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and "error" not in out["train_step_with_head"]
+    # the default config at N > 1 carries the hot-only step of the config BASELINE assigns to that GPU count (here C3), every rank on its
+    # own per-GPU batch, max-over-ranks time
+    c3 = out["other_configs"]["C3"]
+    assert "error" not in c3, c3
+    assert c3["n_gpus"] == 2 and c3["ms_per_step"] > 0 and abs(c3["views_s"] - 2 * 64 / (c3["ms_per_step"] * 1e-3)) < 1e-6 * c3["views_s"]
+    assert set(out["other_configs"]) == {"C3"}
 
 
 def test_default_line_carries_the_other_configs_and_the_noop_control():
@@ -87,7 +99,7 @@ def test_default_line_carries_the_other_configs_and_the_noop_control():
     holds the hot-only steps of C3 / C4 / C5 / C2-compact (`other_configs`) and the per-view route's NO-OP-operator control."""
     out = _run(["--steps", "10", "--warmup", "3", "--cpu-seconds", "1", "--no-e2e"])
     oc = out["other_configs"]
-    for k in ("C3", "C4", "C5", "C2_compact"):
+    for k in ("C3", "C4", "C5", "C2_compact", "C4_fused", "C5_fused"):
         assert "error" not in oc[k], oc[k]
         for f in ("ms_per_step", "views_s", "tile_kernel_ms", "frac_consumed", "walked_mean"):
             assert oc[k][f] > 0, (k, f)
@@ -97,3 +109,12 @@ def test_default_line_carries_the_other_configs_and_the_noop_control():
     assert pv["noop_operator_ms"] > 0 and abs(pv["operator_share_ms"] - (pv["ms_per_step"] - pv["noop_operator_ms"])) < 1e-9
     fr = out["forward_rasterizer"]
     assert 0 < fr["frac_pmc_bytes"] <= fr["frac_of_8TBs"]
+    # rows N1 / N4a in the driver's own line: per operator microseconds, roofline, CPU-oracle baseline, equality with the oracle
+    po, fu = out["pointops"], out["fusion"]
+    assert "error" not in po and "error" not in fu, (po, fu)
+    assert po["all_equal_oracle"] and len(po["ops"]) >= 14
+    for name, o in po["ops"].items():
+        assert o["us"] > 0 and o["roofline"]["frac"] > 0 and o["cpu_baseline"]["value"] > 0 and o["cpu_baseline"]["kind"] == "port", name
+    assert po["ops"]["fps_1024_to_128"]["us_per_selection"] < 0.6                          # (0.84 before round 5; 0.44 measured)
+    for half in ("forward", "backward"):
+        assert fu[half]["us"] > 0 and fu[half]["equals_oracle"] and fu[half]["cpu_baseline"]["value"] > 0

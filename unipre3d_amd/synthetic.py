@@ -18,6 +18,10 @@ CONFIGS = {
     "C3": dict(level="object", P=2048, H=256, W=256, B=16, V=4),
     "C4": dict(level="scene", P=40000, H=480, W=640, B=2, V=8),
     "C5": dict(level="scene", P=200000, H=480, W=640, B=1, V=8),
+    # SURVEY's C4 / C5 rows read "~40 k voxels + fused pixel-Gaussians" (fusion/point_fusion.py:159-168 concatenates the voxels of the
+    # unprojected pixels of the reference views, <= 8 x 480 x 640 before the 2 cm grid sampling): the same shapes with that share added
+    "C4_fused": dict(level="scene", P=120000, H=480, W=640, B=2, V=8),
+    "C5_fused": dict(level="scene", P=350000, H=480, W=640, B=1, V=8),
 }
 
 
