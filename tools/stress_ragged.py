@@ -1,11 +1,17 @@
 """GPU stress of ragged batches: random set sizes (incl. empty and one-Gaussian sets, all three sort routes), both levels, all losses,
-isotropic on/off: the packed fused step (single-pass and two-pass) must equal one fused call per set."""
+isotropic on/off.  PARITY: the packed step's gradient of every set the oracle finishes quickly (<= 2000 Gaussians, not isotropic) goes
+through the one parity rule (tests/arbiter.py::assert_parity, oracle in fp32 and fp64).  CONSISTENCY (HIP vs HIP, not parity evidence): the
+packed fused step (single-pass and two-pass) must equal one fused call per set -- images bit for bit, gradients to 1e-4."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
 from unipre3d_amd import fused, synthetic
 from unipre3d_amd.rasterizer import pack_ragged
 from conftest import rel_l2
+import arbiter
+from oracle import oracle as oracle_mod
+oracle_mod.build()
+orc = {"sets": 0, "bad": 0, "worst_e64": 0.0}
 dev = torch.device("cuda")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
@@ -36,7 +42,20 @@ for it in range(N):
         a, r = hp.grad[o:o + n] * B, ref_g[i]
         e = rel_l2(a.cpu().numpy(), r.cpu().numpy()) if r.abs().sum() > 0 else float(a.abs().sum())
         worst = max(worst, e); ok = ok and e < 1e-4     # (the packed call scales every seed by 1/B: scene-level sums re-round by up to a few 1e-5)
+        if n <= 2000 and not iso and orc["sets"] < 4 * (it + 1):
+            hb = bs[i].to(torch.device("cpu"))
+            try:
+                a32, _ = arbiter.head_grad_arbiter_all(oracle_mod, hb, H, W, kind, np.float32)
+                a64, _ = arbiter.head_grad_arbiter_all(oracle_mod, hb, H, W, kind, np.float64)
+                eg = arbiter.assert_parity(a.t().cpu().numpy()[None], a32, a64, f"case {it} set {i} (n = {n}) packed d(head_out) x B")
+                orc["sets"] += 1; orc["worst_e64"] = max(orc["worst_e64"], eg[0])
+            except AssertionError as ex:
+                orc["sets"] += 1; orc["bad"] += 1
+                print("ORACLE CASE", it, dict(sizes=sizes, set=i, V=V, H=H, W=W, level=level, kind=kind, single_pass=sp), str(ex)[:400])
         o += n
     if not ok:
         bad += 1; print("CASE", it, dict(sizes=sizes, V=V, H=H, W=W, level=level, kind=kind, iso=iso, single_pass=sp))
-print("cases %d bad %d worst gradient rel-L2 %.2e (%.1f s)" % (N, bad, worst, time.time() - t0))
+print("vs oracle (tests/arbiter.py::assert_parity, tol %.0e): sets %d bad %d, worst e64 %.2e, gap passes %d %s"
+      % (arbiter.TOL, orc["sets"], orc["bad"], orc["worst_e64"], len(arbiter.GAP_PASSES), [(w, "%.2e" % e, "%.2e" % g) for (w, e, g) in arbiter.GAP_PASSES[:8]]))
+print("HIP vs HIP (packed vs per-set calls: consistency only, NOT parity; images bit for bit, gradients accepted to 1e-4): cases %d bad %d worst "
+      "gradient rel-L2 %.2e (%.1f s)" % (N, bad, worst, time.time() - t0))
