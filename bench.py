@@ -717,10 +717,8 @@ def per_view_region(batch, B, P, V, H, W, loss_kind, steps=9):
         _rd.FAST_PATH = True
     # the same unchanged double loop captured ONCE into a HIP graph and replayed: the operator holds no host
     # synchronisation, so the B*V forward and B*V backward calls, torch.stack, the loss and autograd's own kernels become one graph launch.
-    # The focal-L2 weight map (a function of gt only, built by the reference from a host list: an H2D copy a capture refuses) is hoisted.
     try:
         graw = batch.raw.clone().requires_grad_(True)
-        w_map = losses.focal_l2_weights(gt, [0.0, 0.0, 0.0], 4, 1) if loss_kind == "focal_l2" else None
 
         def graph_body():
             gs = head.process_object_output(graw, batch.center, batch.offset_scale)
@@ -729,8 +727,7 @@ def per_view_region(batch, B, P, V, H, W, loss_kind, steps=9):
                 pc = {k: v[i].contiguous() for k, v in gs.items()}
                 for v in range(V):
                     imgs.append(renderer.render_predicted(pc, batch.world_view[i, v], batch.full_proj[i, v], batch.camera_center[i, v], batch.bg, cfg)["render"])
-            d2 = (torch.stack(imgs) - gt) ** 2
-            l = (d2 * w_map).mean() if w_map is not None else d2.mean()
+            l = losses.render_loss(torch.stack(imgs), gt, loss_kind)
             l.backward()
             return l
         side = torch.cuda.Stream()
@@ -756,7 +753,7 @@ def per_view_region(batch, B, P, V, H, W, loss_kind, steps=9):
         out["graph_replay_ms"] = 1e3 * (time.perf_counter() - t0) / 20
         out["graph_replay_equals_eager"] = bool(torch.equal(l_static.detach(), l_eager.detach()) and torch.equal(graw.grad, g_eager))
         out["graph_replay_what"] = ("the same double loop (2 x B*V operator calls, torch.stack, loss, autograd) captured once in a torch.cuda.CUDAGraph with "
-                                    "static inputs and replayed; focal-L2's weight map hoisted out of the loss")
+                                    "static inputs and replayed")
         del graph
     except Exception as e:  # noqa: BLE001
         out["graph_replay_ms"] = None

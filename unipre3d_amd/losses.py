@@ -20,7 +20,8 @@ def l2_loss(x, gt):
 def focal_l2_weights(gt: torch.Tensor, bg_color, non_bg_rate: float, bg_rate: float) -> torch.Tensor:
     """(N,1,H,W) per-pixel weight: pixels whose 3 gt channels are all isclose(bg, atol=1e-6, rtol=1e-5)
     get 2*bg/(bg+non_bg), the rest 2*non_bg/(bg+non_bg) (utils/loss_utils.py:28-38)."""
-    bg = torch.as_tensor(bg_color, dtype=gt.dtype, device=gt.device)
+    # 0-dim HOST tensors like the reference's `torch.tensor(bg_color[0])`: no H2D copy per call, so the loss can sit inside a HIP-graph capture
+    bg = [torch.tensor(float(c), dtype=gt.dtype) for c in bg_color]
     is_bg = torch.isclose(gt[:, 0], bg[0], atol=1e-6) & torch.isclose(gt[:, 1], bg[1], atol=1e-6) & \
         torch.isclose(gt[:, 2], bg[2], atol=1e-6)
     w_non = 2 * non_bg_rate / (bg_rate + non_bg_rate)
