@@ -139,6 +139,34 @@ def test_C2_full_shape(oracle_mod):
     _fused_paths(oracle_mod, "C2", b, bd, (7, 1), "focal_l2")
 
 
+@pytest.mark.parametrize("cfg_name,n_items", [("C2", None), ("C3", 2)])
+def test_whole_batch_gradient_against_the_oracle(oracle_mod, cfg_name, n_items):
+    """The headline workload itself under the parity rule, not a sample of it: loss and d loss / d head_out of the WHOLE C2 batch (32 objects x 4
+    views, every view carrying loss, the across-point quaternion normalisation coupling an object's Gaussians) from the fused single-pass
+    step -- exactly what bench.py times -- against the oracle chained through the reference's activations and focal-L2 loss, in fp32 and fp64,
+    all 128 views (tests/arbiter.py::head_grad_arbiter_all).  C3's shape (2048 Gaussians per object, the LDS rank sort) with two objects."""
+    from unipre3d_amd import fused, synthetic
+    from arbiter import head_grad_arbiter_all
+    dev = torch.device("cuda:0")
+    cfg = synthetic.CONFIGS[cfg_name]
+    B, P, V, H, W = n_items or cfg["B"], cfg["P"], cfg["V"], cfg["H"], cfg["W"]
+    b = synthetic.make_batch(B, P, V, H, W, level="object", seed=42)          # the bench's own seed
+    bd = b.to(dev)
+    h = bd.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
+    loss, _, _ = fused.render_loss_fused(h, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt, bd.bg, bd.fov_deg, H, W, level="object",
+                                         offset_scale=bd.offset_scale, loss_kind="focal_l2", return_images=False)
+    loss.backward()
+    torch.cuda.synchronize()
+    a32, l32 = head_grad_arbiter_all(oracle_mod, b, H, W, "focal_l2", np.float32)
+    a64, l64 = head_grad_arbiter_all(oracle_mod, b, H, W, "focal_l2", np.float64)
+    assert abs(loss.item() - l64) <= 1e-5 * abs(l64), (loss.item(), l32, l64)
+    e = assert_parity(h.grad.permute(0, 2, 1).cpu().numpy(), a32, a64, f"{cfg_name} whole batch fused d(head_out)")
+    worst_item = max(rel_l2(h.grad[i].t().cpu().numpy(), a64[i]) for i in range(B))
+    print(f"[{cfg_name} whole batch, {B} objects] loss hip {loss.item():.8f} f64 {l64:.8f}; d(head_out) |hip-f64| {e[0]:.2e} |hip-f32| {e[1]:.2e} "
+          f"|f32-f64| {e[2]:.2e}; worst single object {worst_item:.2e}")
+    assert worst_item <= 10 * TOL
+
+
 def test_C3_full_shape(oracle_mod):
     b, bd = _operator_vs_oracle(oracle_mod, "C3", [(0, 1), (15, 3)])
     _fused_paths(oracle_mod, "C3", b, bd, (9, 2), "focal_l2")
