@@ -276,7 +276,8 @@ def _graph_us(launch, reps, rounds=7):
     how = "hip_graph"
     try:
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
+        # (thread_local: a collective library's watchdog thread querying its events must not invalidate this thread's capture)
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
             for _ in range(reps):
                 launch()
         run = graph.replay
@@ -718,6 +719,8 @@ def per_view_region(batch, B, P, V, H, W, loss_kind, steps=9):
     # the same unchanged double loop captured ONCE into a HIP graph and replayed: the operator holds no host
     # synchronisation, so the B*V forward and B*V backward calls, torch.stack, the loss and autograd's own kernels become one graph launch.
     try:
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("skipped at N > 1 (probe of the single-process call pattern; a capture next to a live process group is not worth the risk to the line)")
         graw = batch.raw.clone().requires_grad_(True)
 
         def graph_body():
@@ -741,7 +744,7 @@ def per_view_region(batch, B, P, V, H, W, loss_kind, steps=9):
         g_eager = graw.grad.clone()
         graw.grad = None
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             l_static = graph_body()
         for _ in range(3):
             graph.replay()
