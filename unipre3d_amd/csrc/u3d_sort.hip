@@ -542,14 +542,18 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
   const int bins = u3d_msd_bins(d.P);
   uint32_t* total = b.sort_hist;
   uint32_t* slice_off = b.sort_hist + (size_t)NV * bins;
-#define LAUNCH(NT, IT, SH)                                                                                                                    \
+#define LAUNCH(NT, IT, SH, BIT)                                                                                                               \
   do {                                                                                                                                        \
     hipLaunchKernelGGL((msd_hist_kernel<NT, IT, SH>), dim3(nblk, NV), dim3(NT), 0, s, u3d_span(d), nblk, b.depth, total, slice_off);          \
     hipLaunchKernelGGL((msd_scatter_kernel<NT, IT, SH>), dim3(nblk, NV), dim3(NT), 0, s, u3d_span(d), nblk, b.depth, b.sort_pairs,            \
                        total, slice_off, b.n_vis, b.sort_over);                                                                               \
-    hipLaunchKernelGGL((bucket_sort_kernel<256, 8, SH>), dim3(bins, NV), dim3(256), 0, s, u3d_span(d), b.sort_pairs, b.sort_keys[0], b.sort_vals[0], \
+    hipLaunchKernelGGL((bucket_sort_kernel<256, BIT, SH>), dim3(bins, NV), dim3(256), 0, s, u3d_span(d), b.sort_pairs, b.sort_keys[0], b.sort_vals[0], \
                        b.sort_keys[1], b.sort_vals[1], b.sort_over, b.rect, b.sorted_id, b.sorted_rect);                                      \
   } while (0)
-  if (d.P <= 65536) LAUNCH(U3D_RADIX_NT_SMALL, U3D_RADIX_IT_SMALL, 18); else LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE, 17);
+  // beyond 256 k Gaussians per set the fuller depth buckets exceed 2048 pairs (C5 + fused pixel-Gaussians, 350 k: the radix fallback through
+  // global memory took 110 us): a bucket's workgroup then holds up to 4096 pairs in LDS
+  if (d.P <= 65536) LAUNCH(U3D_RADIX_NT_SMALL, U3D_RADIX_IT_SMALL, 18, 8);
+  else if (d.P <= 262144) LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE, 17, 8);
+  else LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE, 17, 16);
 #undef LAUNCH
 }
