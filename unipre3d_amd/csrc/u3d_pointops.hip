@@ -279,6 +279,16 @@ __global__ void group_points_kernel(int c, int n, int total, const float* __rest
   out[((size_t)bi * c + ci) * total + e] = points[((size_t)bi * c + ci) * n + src];
 }
 
+// Float accumulation into LDS.  gfx950's ds_add_f32 retires ~0.3 lane-updates per clock and CU whatever the addresses (tools/ub/ldsatomic.hip:
+// 204 G/s chip-wide; integer LDS atomics run at 7 - 14 per clock), a compare-and-swap on the word at 2.3 - 4.6 -- unless many lanes of a wave
+// hit ONE address, where the retry loop collapses (0.06).  So: one compare-and-swap attempt, and only the lanes that lost it (another lane of
+// the wave, or another wave, touched the word in between) take the hardware float atomic.
+__device__ __forceinline__ void lds_add_f32(float* addr, float v) {
+  unsigned* w = reinterpret_cast<unsigned*>(addr);
+  const unsigned old = *w;
+  if (atomicCAS(w, old, __float_as_uint(__uint_as_float(old) + v)) != old) unsafeAtomicAdd(addr, v);
+}
+
 // group / gather gradient: grad_points[b][c][idx[b][e]] += grad_out[b][c][e].  The reference (and rounds 1-4 here) issue one GLOBAL float
 // atomic per element; ball-query index sets repeat their first hit as padding, so thousands of them land on one address (3.0 ms at
 // the transformer shape).  Here a workgroup owns `cb` channel rows of one cloud in LDS ([cb][n] floats), accumulates with LDS atomics
@@ -294,14 +304,45 @@ __global__ __launch_bounds__(256) void group_points_grad_lds_kernel(int c, int n
   __syncthreads();
   const int32_t* ip = idx + (size_t)bi * total;
   const float* go = grad_out + ((size_t)bi * c + c0) * total;
-  for (int e = threadIdx.x; e < total; e += 256) {
-    const int dst = ip[e];
+  const int lane = threadIdx.x & 63;
+  for (int e0 = 0; e0 < total; e0 += 256) {         // (wave-uniform trip count: the run merge below shuffles across the wave)
+    const int e = e0 + threadIdx.x;
+    const bool active = e < total;
+    const int dst = active ? ip[e] : 0;
     float g[CB];                                    // all loads of the step in flight before the first LDS atomic
 #pragma unroll
-    for (int cc = 0; cc < CB; ++cc) g[cc] = cc < nc ? go[(size_t)cc * total + e] : 0.f;
+    for (int cc = 0; cc < CB; ++cc) g[cc] = (active && cc < nc) ? go[(size_t)cc * total + e] : 0.f;
+    // Ball-query index sets pad every group with copies of its first hit: runs of EQUAL CONSECUTIVE destinations, which would meet in one LDS
+    // word (the compare-and-swap collapses there).  A wave that holds such a run sums it first -- segmented inclusive scan over the run, the
+    // run's last lane keeps the total -- and only the tails update LDS.  Waves without adjacent duplicates (gather, three_nn-style indices)
+    // skip this.
+    const int key = active ? dst : -1 - lane;
+    const int prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || prev != key;
+    bool tail = true;
+    if (__ballot(!head) != 0ull) {
+      int rs = head ? lane : 0;                      // first lane of this lane's run: running maximum of the head positions
 #pragma unroll
-    for (int cc = 0; cc < CB; ++cc)
-      if (cc < nc) unsafeAtomicAdd(&s_acc[cc * n + dst], g[cc]);
+      for (int st = 1; st < 64; st <<= 1) {
+        const int o = __shfl_up(rs, st);
+        if (lane >= st) rs = max(rs, o);
+      }
+#pragma unroll
+      for (int cc = 0; cc < CB; ++cc) {
+#pragma unroll
+        for (int st = 1; st < 64; st <<= 1) {
+          const float o = __shfl_up(g[cc], st);
+          if (lane - st >= rs) g[cc] += o;
+        }
+      }
+      const int next = __shfl_down(key, 1);
+      tail = lane == 63 || next != key;
+    }
+    if (active && tail) {
+#pragma unroll
+      for (int cc = 0; cc < CB; ++cc)
+        if (cc < nc) lds_add_f32(&s_acc[cc * n + dst], g[cc]);
+    }
   }
   __syncthreads();
   float* gp = grad_points + ((size_t)bi * c + c0) * n;
@@ -444,9 +485,9 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_lds_kernel(int c, 
 #pragma unroll
     for (int cc = 0; cc < CB; ++cc)
       if (cc < nc) {
-        unsafeAtomicAdd(&s_acc[cc * m + i0], g[cc] * w0);
-        unsafeAtomicAdd(&s_acc[cc * m + i1], g[cc] * w1);
-        unsafeAtomicAdd(&s_acc[cc * m + i2], g[cc] * w2);
+        lds_add_f32(&s_acc[cc * m + i0], g[cc] * w0);
+        lds_add_f32(&s_acc[cc * m + i1], g[cc] * w1);
+        lds_add_f32(&s_acc[cc * m + i2], g[cc] * w2);
       }
   }
   __syncthreads();
