@@ -115,6 +115,9 @@ def issue_roofline(config: str, default_path: bool, measured_ms: float):
             "transcendental_per_launch": trans, "fma_mul_add_per_launch": fma, "floor_ms_lower": 1e3 * lower, "floor_ms_by_class": 1e3 * by_class,
             "kernel_ms_rocprof": kernel_ms, "frac_lower": 1e3 * lower / kernel_ms, "frac_by_class": 1e3 * by_class / kernel_ms,
             "cycles_per_valu_instruction_per_simd": cycles * N_SIMD / valu, "shader_cycles_per_launch": cycles, "class_cycles": ISSUE_CYCLES,
+            "reading": ("frac_by_class above 1 means the kernel issues its mix faster than the calibration predicts (the class costs were measured on dependent "
+                        "chains; round 5's exponent run is mostly independent multiplies): read it as 'at the issue floor', not as an error") if 1e3 * by_class / kernel_ms > 1.0
+                       else "floor / measured duration of the tile kernel alone",
             "source": f"profiles/{prof['_round']}/sq_issue_{config}.json (committed rocprofv3 --pmc passes of this command; NOT measured in this "
                       f"run; class costs: builder-calibrated micro-benchmarks, profiles/r01/valu_instruction_classes.txt)"}
 
