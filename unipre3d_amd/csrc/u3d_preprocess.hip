@@ -141,7 +141,7 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     for (int e = threadIdx.x; e < (nv1 - nv0) * msd_bins; e += U3D_BLOCK) msd_total[(size_t)(blockIdx.y * vpi + nv0) * msd_bins + e] = 0u;
   }
   // (sorted_id != null: P <= 256, the block owns the whole set -> the per-view depth sort is fused in, see below)
-  __shared__ unsigned long long s_keys[U3D_BLOCK];
+  __shared__ __attribute__((aligned(16))) unsigned long long s_keys[U3D_BLOCK];
   __shared__ uint2 s_rects[U3D_BLOCK];
   // One thread = one Gaussian of set blockIdx.y; it walks the views [v0, v1) of that set, so the view-independent work
   // (head activations, Sigma, SH coefficient fetch) is done once.  blockIdx.z splits the views when P is small.
@@ -311,26 +311,32 @@ __global__ __launch_bounds__(U3D_BLOCK) void preprocess_fwd_kernel(
     if ((threadIdx.x & 63) == 0 && touched) atomicAdd(&num_rendered[view], touched);
   }
   if (sorted_id) {
-    // fused per-view depth sort (same result as depth_sort_lds_kernel): bitonic network over 256 (depth bits, index) keys
+    // fused per-view depth sort (same result as depth_sort_lds_kernel) of the block's 256 (depth bits, index) keys.  Round 5: by RANK -- every
+    // thread counts the keys smaller than its own from LDS broadcast reads and writes its key to that position: 3 barriers instead of the 36
+    // of the bitonic network this replaced (the kernel is latency-bound: ~2 us of its 10 at C2).  A culled slot's key is ~0 with the thread
+    // index below it, so all 256 keys are distinct and the ranks are a permutation.
     const int tid = threadIdx.x;
-    __syncthreads();               // previous view's readers are done with s_keys / s_rects
-    s_keys[tid] = sort_key;
+    __shared__ unsigned long long s_sorted[U3D_BLOCK];
+    __syncthreads();               // previous view's readers are done with s_keys / s_rects / s_sorted
+    const unsigned long long mine = sort_key != ~0ull ? sort_key : (0xFFFFFFFF00000000ull | (uint32_t)tid);
+    s_keys[tid] = mine;
     s_rects[tid] = sort_rect;
     __syncthreads();
-    for (int k = 2; k <= U3D_BLOCK; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        const int ixj = tid ^ j;
-        if (ixj > tid) {
-          const unsigned long long a = s_keys[tid], b2 = s_keys[ixj];
-          if ((a > b2) == ((tid & k) == 0)) { s_keys[tid] = b2; s_keys[ixj] = a; }
-        }
-        __syncthreads();
+    {
+      int rank = 0;
+      const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(s_keys);
+#pragma unroll 8
+      for (int q = 0; q < U3D_BLOCK / 2; ++q) {
+        const ulonglong2 two = k2[q];          // the same address in every lane: a broadcast
+        rank += (two.x < mine ? 1 : 0) + (two.y < mine ? 1 : 0);
       }
+      s_sorted[rank] = mine;
     }
-    const unsigned long long kk = s_keys[tid];
-    const bool vis = kk != ~0ull;
+    __syncthreads();
+    const unsigned long long kk = s_sorted[tid];
+    const bool vis = (uint32_t)(kk >> 32) != 0xFFFFFFFFu;
     if (tid == 0 && !vis) n_vis[view] = 0;
-    if (vis && (tid == U3D_BLOCK - 1 || s_keys[tid + 1] == ~0ull)) n_vis[view] = (uint32_t)(tid + 1);
+    if (vis && (tid == U3D_BLOCK - 1 || (uint32_t)(s_sorted[tid + 1] >> 32) == 0xFFFFFFFFu)) n_vis[view] = (uint32_t)(tid + 1);
     if (tid < P) {
       const uint32_t id = vis ? (uint32_t)kk : 0u;
       sorted_id[pbase + tid] = id;
