@@ -26,8 +26,8 @@
 #define U3D_RADIX_IT_LARGE 4
 #endif
 static inline int u3d_radix_tile(int P) { return P <= 65536 ? U3D_RADIX_NT_SMALL * U3D_RADIX_IT_SMALL : U3D_RADIX_NT_LARGE * U3D_RADIX_IT_LARGE; }
-#define U3D_MSD_BINS_MAX 1024          /* depth buckets of the large-P sort's first partition (u3d_sort.hip): 512, or 1024 beyond 64 k per view */
-static inline int u3d_msd_bins(int P) { return P <= 65536 ? 512 : 1024; }
+#define U3D_MSD_BINS_MAX 2048          /* depth buckets of the large-P sort's first partition (u3d_sort.hip): 512, 1024 beyond 64 k per view, 2048 beyond 256 k */
+static inline int u3d_msd_bins(int P) { return P <= 65536 ? 512 : (P <= 262144 ? 1024 : 2048); }
 #define U3D_MSD_KEY_BASE 0x3E4CCCCDu   /* bits of 0.2f */
 
 // Per-call view of the carved scratch buffers (device pointers; built on the host).

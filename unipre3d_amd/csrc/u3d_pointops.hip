@@ -558,7 +558,19 @@ int u3d_furthest_point_sampling(int b, int n, int m, const float* points, float*
   }
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)n * 3 * sizeof(float);
-#define FPS_CM(T, P, CM) hipLaunchKernelGGL((fps_kernel<T, P, CM>), dim3(b), dim3(T), lds, s, n, m, lg, points, idx)
+  // (clouds beyond 5461 points stage more than 64 KB: opt in to the larger dynamic LDS size, once per instantiation)
+#define FPS_CM(T, P, CM)                                                                                                             \
+  do {                                                                                                                               \
+    if (lds > 65536) {                                                                                                               \
+      static bool big_lds = false;                                                                                                   \
+      if (!big_lds) {                                                                                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<T, P, CM>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                  8192 * 3 * (int)sizeof(float));                                                                    \
+        big_lds = true;                                                                                                              \
+      }                                                                                                                              \
+    }                                                                                                                                \
+    hipLaunchKernelGGL((fps_kernel<T, P, CM>), dim3(b), dim3(T), lds, s, n, m, lg, points, idx);                                     \
+  } while (0)
 #define FPS(T, P)                                                    \
   do {                                                               \
     if (g_contraction == U3D_PO_FMA_LLVM) FPS_CM(T, P, U3D_PO_FMA_LLVM);        \

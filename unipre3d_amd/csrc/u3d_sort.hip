@@ -242,7 +242,8 @@ __global__ __launch_bounds__(NT) void depth_sort_block_radix_kernel(U3DSpan span
 // C4 5.0 + 16.0 + 20.3 us.  Sorted positions at and beyond n_vis[view] are NOT written: nothing reads them (tile_stage stops there).
 constexpr uint32_t MSD_KEY_BASE = U3D_MSD_KEY_BASE;   // bits of 0.2f
 // SHIFT = 18: 512 buckets, 32 per octave (up to 64 k Gaussians per view); SHIFT = 17: 1024 buckets, 64 per octave (beyond: halves the
-// buckets, so that a 256-thread workgroup with 16 KB of LDS still holds one and all of them are resident at once)
+// buckets, so that a 256-thread workgroup with 16 KB of LDS still holds one and all of them are resident at once); SHIFT = 16: 2048 buckets
+// beyond 256 k per set (hist / scatter threads then own two buckets each)
 template <int SHIFT> struct Msd { static constexpr int BINS = 16 << (23 - SHIFT); static_assert(BINS <= U3D_MSD_BINS_MAX, "scratch is carved for this many"); };
 constexpr int SUB_BITS = 8, SUB_BINS = 1 << SUB_BITS;
 constexpr int SUB_MAX = 512;                          // largest sub-bin ranked by all-pairs comparison
@@ -254,13 +255,12 @@ template <int NT, int ITEMS, int SHIFT>
 __global__ __launch_bounds__(NT) void msd_hist_kernel(U3DSpan span, int nblk, const float* __restrict__ depth, uint32_t* __restrict__ total,
                                                       uint32_t* __restrict__ slice_off) {
   constexpr int MSD_BINS = Msd<SHIFT>::BINS;
-  static_assert(NT >= MSD_BINS, "one thread per bucket");
   __shared__ uint32_t h[MSD_BINS];
   const int view = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   int P;
   size_t base;
   u3d_view_span(span, view, P, base);
-  if (tid < MSD_BINS) h[tid] = 0;
+  for (int t = tid; t < MSD_BINS; t += NT) h[t] = 0;
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
@@ -271,9 +271,9 @@ __global__ __launch_bounds__(NT) void msd_hist_kernel(U3DSpan span, int nblk, co
     }
   }
   __syncthreads();
-  if (tid < MSD_BINS) {
-    const uint32_t c = h[tid];
-    slice_off[((size_t)view * nblk + blk) * MSD_BINS + tid] = c ? atomicAdd(&total[(size_t)view * MSD_BINS + tid], c) : 0u;
+  for (int t = tid; t < MSD_BINS; t += NT) {
+    const uint32_t c = h[t];
+    slice_off[((size_t)view * nblk + blk) * MSD_BINS + t] = c ? atomicAdd(&total[(size_t)view * MSD_BINS + t], c) : 0u;
   }
 }
 
@@ -283,37 +283,46 @@ __global__ __launch_bounds__(NT) void msd_scatter_kernel(U3DSpan span, int nblk,
                                                          const uint32_t* __restrict__ total, const uint32_t* __restrict__ slice_off,
                                                          uint32_t* __restrict__ n_vis, uint32_t* __restrict__ bucket_off) {
   constexpr int MSD_BINS = Msd<SHIFT>::BINS;
-  static_assert(NT >= MSD_BINS, "one thread per bucket in the prologue");
+  constexpr int BPT = MSD_BINS > NT ? MSD_BINS / NT : 1;   // consecutive buckets per thread of the prologue's scan
+  constexpr int SCAN_T = MSD_BINS / BPT;                    // threads taking part in it (a multiple of 64)
+  static_assert(MSD_BINS % BPT == 0 && SCAN_T <= NT && SCAN_T % 64 == 0, "the scan covers the buckets with whole waves");
   __shared__ uint32_t s_base[MSD_BINS], s_cnt[MSD_BINS];
-  __shared__ uint32_t s_wave[MSD_BINS / 64];
+  __shared__ uint32_t s_wave[SCAN_T / 64];
   const int view = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
   const uint32_t lane = u3d_lane_id();
   int P;
   size_t base;
   u3d_view_span(span, view, P, base);
   {
-    uint32_t tot = 0, inc = 0;
-    if (tid < MSD_BINS) {
-      tot = total[(size_t)view * MSD_BINS + tid];
-      inc = tot;   // inclusive scan of the bucket totals: shuffles inside each of the first waves, then the wave totals
+    uint32_t tot[BPT], sum = 0, inc = 0;
+    if (tid < SCAN_T) {
+#pragma unroll
+      for (int q = 0; q < BPT; ++q) {
+        tot[q] = total[(size_t)view * MSD_BINS + tid * BPT + q];
+        sum += tot[q];
+        s_cnt[tid * BPT + q] = 0;
+      }
+      inc = sum;   // inclusive scan of the threads' bucket totals: shuffles inside each of the first waves, then the wave totals
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
         if ((int)lane >= o) inc += v;
       }
       if (lane == 63) s_wave[wave] = inc;
-      s_cnt[tid] = 0;
     }
     __syncthreads();
-    if (tid < MSD_BINS) {
+    if (tid < SCAN_T) {
       uint32_t off = 0;
       for (int w = 0; w < wave; ++w) off += s_wave[w];
-      const uint32_t start = off + inc - tot;
-      if (blk == 0) {
-        bucket_off[(size_t)view * (MSD_BINS + 1) + tid] = start;
-        if (tid == MSD_BINS - 1) { bucket_off[(size_t)view * (MSD_BINS + 1) + MSD_BINS] = off + inc; n_vis[view] = off + inc; }
+      uint32_t start = off + inc - sum;
+#pragma unroll
+      for (int q = 0; q < BPT; ++q) {
+        const int bkt = tid * BPT + q;
+        if (blk == 0) bucket_off[(size_t)view * (MSD_BINS + 1) + bkt] = start;
+        s_base[bkt] = start + slice_off[((size_t)view * nblk + blk) * MSD_BINS + bkt];
+        start += tot[q];
       }
-      s_base[tid] = start + slice_off[((size_t)view * nblk + blk) * MSD_BINS + tid];
+      if (blk == 0 && tid == SCAN_T - 1) { bucket_off[(size_t)view * (MSD_BINS + 1) + MSD_BINS] = start; n_vis[view] = start; }
     }
     __syncthreads();
   }
@@ -550,10 +559,11 @@ void u3d_launch_depth_sort(const u3d_raster_desc& d, const U3DBuffers& b, const 
     hipLaunchKernelGGL((bucket_sort_kernel<256, BIT, SH>), dim3(bins, NV), dim3(256), 0, s, u3d_span(d), b.sort_pairs, b.sort_keys[0], b.sort_vals[0], \
                        b.sort_keys[1], b.sort_vals[1], b.sort_over, b.rect, b.sorted_id, b.sorted_rect);                                      \
   } while (0)
-  // beyond 256 k Gaussians per set the fuller depth buckets exceed 2048 pairs (C5 + fused pixel-Gaussians, 350 k: the radix fallback through
-  // global memory took 110 us): a bucket's workgroup then holds up to 4096 pairs in LDS
+  // beyond 256 k Gaussians per set the fuller depth buckets exceed the 2048 pairs a bucket's workgroup ranks in LDS (C5 + fused
+  // pixel-Gaussians, 350 k: the radix fallback through global memory took 110 us): 2048 buckets there, 128 per octave (44.7 us; 1024 buckets
+  // with 4096-pair workgroups measured 49.9)
   if (d.P <= 65536) LAUNCH(U3D_RADIX_NT_SMALL, U3D_RADIX_IT_SMALL, 18, 8);
   else if (d.P <= 262144) LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE, 17, 8);
-  else LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE, 17, 16);
+  else LAUNCH(U3D_RADIX_NT_LARGE, U3D_RADIX_IT_LARGE, 16, 8);
 #undef LAUNCH
 }
