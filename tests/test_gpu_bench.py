@@ -13,13 +13,41 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "data", "config", "roofline")
 
 
-def _run(args, env=None, timeout=900):
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
-                         env=dict(os.environ, **(env or {})))
-    assert res.returncode == 0, res.stderr[-3000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
-    return json.loads(lines[0])
+LINE_MAX = 6000          # the driver parses the LAST stdout line; round 5's 29 KB object came back `parsed: null`
+
+
+def _check_compact(stdout):
+    """The LAST stdout line is the contract object: compact JSON, <= 6 KB, with roofline / cpu_baseline / config.workload."""
+    last = stdout.rstrip("\n").splitlines()[-1]
+    assert len(last) < LINE_MAX, len(last)
+    line = json.loads(last)
+    for k in CONTRACT:
+        assert k in line, k
+    assert line["roofline"]["frac"] > 0 and line["config"]["workload"] and "extra_keys" in line
+    assert [l for l in stdout.splitlines() if l.startswith("{")] == [last], "exactly ONE JSON line on stdout"
+    return line
+
+
+def _run(args, env=None, timeout=900, compact=False):
+    """Runs bench.py; returns the FULL record (bench_full.json, where the per-operator detail lives) after checking the compact
+    line the driver parses -- whose contract keys must equal the record's."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        full = os.path.join(td, "bench_full.json")
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                             env=dict(os.environ, U3D_BENCH_FULL_JSON=full, **(env or {})))
+        assert res.returncode == 0, res.stderr[-3000:]
+        line = _check_compact(res.stdout)
+        out = json.load(open(full))
+    assert line["full_record"] == full
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "data"):
+        assert line[k] == out[k], k
+    assert abs(line["value"] - out["value"]) <= 1e-5 * out["value"] and abs(line["roofline"]["frac"] - out["roofline"]["frac"]) <= 1e-4 * out["roofline"]["frac"]
+    if "cpu_baseline" in out:
+        assert line["cpu_baseline"]["kind"] == out["cpu_baseline"]["kind"] and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+    for k in ("scale_ok", "scale_verdict", "rccl_ranks"):
+        assert line[k] == out[k], k
+    return (out, line) if compact else out
 
 
 def test_bench_line_single_gpu_small_config():
@@ -39,8 +67,8 @@ def test_bench_line_single_gpu_small_config():
 
 
 def test_bench_self_launches_two_ranks():
-    out = _run(["--gpus", "2", "--config", "C1", "--steps", "4", "--warmup", "1", "--cpu-seconds", "1"],
-               env={"U3D_BENCH_SHARE_GPU": "1", "U3D_BENCH_EXTRAS_BUDGET_S": "240"})
+    out, line = _run(["--gpus", "2", "--config", "C1", "--steps", "4", "--warmup", "1", "--cpu-seconds", "1"],
+                     env={"U3D_BENCH_SHARE_GPU": "1", "U3D_BENCH_EXTRAS_BUDGET_S": "240"}, compact=True)
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["views_per_step"] == 16
     # an N > 1 line is field for field as complete as the N = 1 line: roofline AND cpu_baseline (rank 0 times it
     # while the other ranks wait at the host barrier), plus the rows N1 / N4a
@@ -61,6 +89,10 @@ def test_bench_self_launches_two_ranks():
         assert k in out, k
     assert out["rccl_ranks"] == 0 and out["collective_backend"] == "gloo" and out["scale_ok"] is False
     assert "gloo" in out["scale_note"] and "rccl_ranks = 0" in out["scale_note"]          # ... and the line says why
+    assert line["scale_ok"] is False and line["scale_verdict"].startswith("fail: rccl_ranks 0 != n_gpus 2") and "gloo" in line["scale_verdict"]
+    for k in ("rccl_ranks", "train_region_value", "n1_same_region", "speedup_over_n1_same_region", "scale_verdict"):
+        assert k in line, k                                                               # ... at the top level of the COMPACT line
+    assert line["extra_keys"]["pointops_all_equal_oracle"] is True and line["extra_keys"]["fusion"]["forward"]["equals_oracle"] is True
     assert out["train_region_value"] == e2e["value"] and out["n1_same_region"] == e2e["n1_same_region"]["value"]
     assert out["gradient_bytes_all_reduced_per_step"] == 4 * 29_464_215 and out["speedup_over_n1_same_region"] > 0
     # the same launch quoting the step WITH the exchange in it as `value`
@@ -80,11 +112,14 @@ def test_bench_under_torch_distributed_run():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
            "--no-cpu-baseline", "--no-e2e", "--no-next-rows"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, U3D_BENCH_BACKEND="gloo"))
-    assert res.returncode == 0, res.stderr[-3000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
-    out = json.loads(lines[0])
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        full = os.path.join(td, "bench_full.json")
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, U3D_BENCH_BACKEND="gloo", U3D_BENCH_FULL_JSON=full))
+        assert res.returncode == 0, res.stderr[-3000:]
+        line = _check_compact(res.stdout)
+        out = json.load(open(full))
+    assert line["n_gpus"] == 2 and line["extra_keys"]["other_configs"]["C3"][0] > 0
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and "error" not in out["train_step_with_head"]
     # the default config at N > 1 carries the hot-only step of the config BASELINE assigns to that GPU count (here C3), every rank on its
     # own per-GPU batch, max-over-ranks time
@@ -97,7 +132,13 @@ def test_bench_under_torch_distributed_run():
 def test_default_line_carries_the_other_configs_and_the_noop_control():
     """The driver's own command (`python bench.py --gpus 1`, here with fewer steps): after the contractual C2 region the line
     holds the hot-only steps of C3 / C4 / C5 / C2-compact (`other_configs`) and the per-view route's NO-OP-operator control."""
-    out = _run(["--steps", "10", "--warmup", "3", "--cpu-seconds", "1", "--no-e2e"])
+    out, line = _run(["--steps", "10", "--warmup", "3", "--cpu-seconds", "1", "--no-e2e"], compact=True)
+    ex = line["extra_keys"]
+    assert "extra_keys_dropped" not in line, line.get("extra_keys_dropped")
+    assert set(ex["other_configs"]) == {"C3", "C4", "C5", "C2_compact", "C4_fused", "C5_fused"} and len(ex["pointops_us"]) >= 14
+    assert ex["per_view"]["operator_gpu_ms"] > 0 and ex["per_view"]["operator_host_ms"] > 0
+    assert line["roofline"]["kernel"] == "render_fb" and line["roofline"]["traffic"] and line["roofline"]["frac_consumed"] > 0
+    assert line["scale_verdict"].startswith("n/a")
     oc = out["other_configs"]
     for k in ("C3", "C4", "C5", "C2_compact", "C4_fused", "C5_fused"):
         assert "error" not in oc[k], oc[k]
@@ -107,6 +148,10 @@ def test_default_line_carries_the_other_configs_and_the_noop_control():
     pv = out["per_view_dropin"]
     assert "error" not in pv, pv
     assert pv["noop_operator_ms"] > 0 and abs(pv["operator_share_ms"] - (pv["ms_per_step"] - pv["noop_operator_ms"])) < 1e-9
+    # the operator's own share, measured directly: its kernels' HIP-event time per step and the host time of its 2 x B*V bare binding calls
+    assert "operator_error" not in pv, pv.get("operator_error")
+    assert 0 < pv["operator_gpu_ms"] < pv["ms_per_step"] and 0 < pv["operator_host_ms"] < pv["ms_per_step"]
+    assert pv["operator_gpu_scopes_per_step"] >= 4 * 128                               # 2 scopes forward + 2 backward per view
     fr = out["forward_rasterizer"]
     assert 0 < fr["frac_pmc_bytes"] <= fr["frac_of_8TBs"]
     # rows N1 / N4a in the driver's own line: per operator microseconds, roofline, CPU-oracle baseline, equality with the oracle
