@@ -54,6 +54,11 @@ def _lib(dtype):
         fwd.restype = vp
         fwd.argtypes = [ctypes.c_int] * 3 + [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, real, vp, vp,
                                              vp, vp, vp, real, real, ctypes.c_int, vp, vp, vp]
+        fwd_d = getattr(lib, pre + "forward_discrete")
+        fwd_d.restype = vp
+        fwd_d.argtypes = list(fwd.argtypes) + [vp, vp, vp]
+        getattr(lib, pre + "state_discrete").argtypes = [vp, vp, vp]
+        getattr(lib, pre + "state_discrete").restype = None
         bwd = getattr(lib, pre + "backward")
         bwd.restype = None
         bwd.argtypes = [vp] * 11
@@ -161,8 +166,13 @@ class OracleRender:
 def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, image_height, image_width, tanfovx, tanfovy,
             shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, sh_degree=0,
             scale_modifier=1.0, antialiasing=True, prefiltered=False, exact_aa_grad=False,
-            dtype=np.float32) -> OracleRender:
-    """CPU restatement of `GaussianRasterizer.forward` (call site gaussian_renderer/__init__.py:89-97)."""
+            dtype=np.float32, discrete_from: Optional["OracleRender"] = None) -> OracleRender:
+    """CPU restatement of `GaussianRasterizer.forward` (call site gaussian_renderer/__init__.py:89-97).
+
+    discrete_from: an OracleRender of the SAME inputs (normally the fp32 one) whose discrete per-Gaussian decisions -- survival of the
+    culls, integer radius, tile rectangle, and the fp32 depth that is the sort key (ties -> index) -- this evaluation takes over while
+    computing every continuous quantity in its own dtype.  fp64 + discrete_from=r32 is the parity rule's arbiter: the reference
+    operator is fp32, so those integers ARE the reference's semantics (raster_oracle.c: forward_impl)."""
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
     if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -194,10 +204,31 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, image_height
     radii = np.zeros((max(P, 1),), dtype=np.int32)
     flags = (FLAG_ANTIALIASING if antialiasing else 0) | (FLAG_PREFILTERED if prefiltered else 0) | \
             (FLAG_EXACT_AA_GRAD if exact_aa_grad else 0)
-    st = getattr(lib, pre + "forward")(P, int(sh_degree), M, _ptr(bgc), W, H, _ptr(means3D), _ptr(shs),
-                                       _ptr(colors_precomp), _ptr(opacities), _ptr(scales), real(scale_modifier),
-                                       _ptr(rotations), _ptr(cov3D_precomp), _ptr(view), _ptr(proj), _ptr(cam),
-                                       real(tanfovx), real(tanfovy), flags, _ptr(color), _ptr(invd), _ptr(radii))
+    common = (P, int(sh_degree), M, _ptr(bgc), W, H, _ptr(means3D), _ptr(shs), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
+              real(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(view), _ptr(proj), _ptr(cam), real(tanfovx), real(tanfovy),
+              flags, _ptr(color), _ptr(invd), _ptr(radii))
+    own = None
+    if isinstance(discrete_from, str):
+        # "fp32": run the fp32 restatement on the same inputs (rounded to fp32) for the discrete decisions
+        assert discrete_from == "fp32", discrete_from
+        f32 = lambda x: None if x is None else np.asarray(x, dtype=np.float32)
+        own = discrete_from = forward(f32(means3D), f32(opacities), f32(view), f32(proj), f32(cam), f32(bgc), H, W, tanfovx, tanfovy,
+                                      shs=f32(shs), colors_precomp=f32(colors_precomp), scales=f32(scales), rotations=f32(rotations),
+                                      cov3D_precomp=f32(cov3D_precomp), sh_degree=sh_degree, scale_modifier=scale_modifier,
+                                      antialiasing=antialiasing, prefiltered=prefiltered, exact_aa_grad=exact_aa_grad, dtype=np.float32)
+    if discrete_from is None:
+        st = getattr(lib, pre + "forward")(*common)
+    else:
+        d = discrete_from
+        assert d.P == P and d.H == H and d.W == W and d._state, "discrete_from: an open OracleRender of the same inputs"
+        dl, dpre, _ = _lib(d.dtype)
+        rect = np.zeros((max(P, 1), 4), np.int32)
+        depth = np.zeros((max(P, 1),), np.float32)
+        getattr(dl, dpre + "state_discrete")(ctypes.c_void_p(d._state), _ptr(rect), _ptr(depth))
+        drad = np.ascontiguousarray(np.concatenate([d.radii, np.zeros(max(P, 1) - P, np.int32)]).astype(np.int32))
+        st = getattr(lib, pre + "forward_discrete")(*common, _ptr(drad), _ptr(rect), _ptr(depth))
+        if own is not None:
+            own.close()
     nr = int(getattr(lib, pre + "num_rendered")(ctypes.c_void_p(st)))
     return OracleRender(color=color, invdepth=invd, radii=radii[:P], num_rendered=nr, dtype=dtype, P=P, M=M,
                         H=H, W=W, _state=st)

@@ -281,11 +281,18 @@ void FN(free)(oracle_state *s) {
  * shs: (P,M,3) or NULL; colors_precomp: (P,3) or NULL; scales (P,3)+rotations (P,4) or
  * cov3D_precomp (P,6).  out_color (3,H,W), out_invdepth (H,W), radii (P).
  * Returns an opaque state for backward / inspection (free with *_free). */
-oracle_state *FN(forward)(int P, int D, int M, const REAL *bg, int W, int H, const REAL *means3D, const REAL *shs,
-                          const REAL *colors_precomp, const REAL *opacities, const REAL *scales,
-                          REAL scale_modifier, const REAL *rotations, const REAL *cov3D_precomp,
-                          const REAL *viewmatrix, const REAL *projmatrix, const REAL *campos, REAL tan_fovx,
-                          REAL tan_fovy, int flags, REAL *out_color, REAL *out_invdepth, int *radii_out) {
+/* disc_*: the DISCRETE per-Gaussian decisions of another evaluation (NULL: decide here).  The reference operator is fp32: which
+ * Gaussians survive the culls, their integer radius and tile rectangle, and the ORDER its (tile | fp32 depth bits) key with
+ * stable index ties puts them in are integer facts of fp32 arithmetic.  An fp64 evaluation that re-decides them in fp64 is an
+ * arbiter of a DIFFERENT discrete problem whenever two fp32 depths tie (routine at 10^5 Gaussians per view) or a radius sits on a
+ * ceil boundary.  With the overrides the fp64 build keeps every continuous quantity in fp64 and takes visibility / radius /
+ * rectangle / sort key from the fp32 restatement (oracle.forward(..., discrete_from=r32)): the arbiter the parity rule uses. */
+static oracle_state *forward_impl(int P, int D, int M, const REAL *bg, int W, int H, const REAL *means3D, const REAL *shs,
+                                  const REAL *colors_precomp, const REAL *opacities, const REAL *scales,
+                                  REAL scale_modifier, const REAL *rotations, const REAL *cov3D_precomp,
+                                  const REAL *viewmatrix, const REAL *projmatrix, const REAL *campos, REAL tan_fovx,
+                                  REAL tan_fovy, int flags, REAL *out_color, REAL *out_invdepth, int *radii_out,
+                                  const int *disc_radii, const int *disc_rect, const float *disc_depth) {
   oracle_state *s = (oracle_state *)calloc(1, sizeof(oracle_state));
   s->P = P; s->D = D; s->M = M; s->W = W; s->H = H; s->flags = flags;
   s->tiles_x = (W + TILE - 1) / TILE; s->tiles_y = (H + TILE - 1) / TILE;
@@ -320,7 +327,8 @@ oracle_state *FN(forward)(int P, int D, int M, const REAL *bg, int W, int H, con
     const REAL *p = means3D + 3 * idx;
     REAL p_view[3], p_hom[4];
     xform4x3(p, viewmatrix, p_view);
-    if (p_view[2] <= C(0.2)) continue;                       /* near cull (R4 step 1) */
+    if (disc_radii) { if (disc_radii[idx] <= 0) continue; }   /* every cull below was decided by the fp32 evaluation */
+    else if (p_view[2] <= C(0.2)) continue;                  /* near cull (R4 step 1) */
     xform4x4(p, projmatrix, p_hom);
     REAL p_w = C(1) / (p_hom[3] + C(0.0000001));             /* R4 step 2 */
     REAL p_proj[2] = {p_hom[0] * p_w, p_hom[1] * p_w};
@@ -338,7 +346,7 @@ oracle_state *FN(forward)(int P, int D, int M, const REAL *bg, int W, int H, con
     REAL h_scaling = C(1);
     if (antialiasing) h_scaling = R_SQRT(RMAX(C(0.000025), det_cov / det_plus));
     REAL det = det_plus;
-    if (det == C(0)) continue;
+    if (det == C(0) && !disc_radii) continue;
     REAL det_inv = C(1) / det;
     REAL conic[3] = {abc[2] * det_inv, -abc[1] * det_inv, abc[0] * det_inv};
     REAL mid = C(0.5) * (abc[0] + abc[2]);                    /* R4 step 6 */
@@ -347,8 +355,13 @@ oracle_state *FN(forward)(int P, int D, int M, const REAL *bg, int W, int H, con
     REAL my_radius = R_CEIL(C(3) * R_SQRT(RMAX(lambda1, lambda2)));
     REAL point_image[2] = {ndc2pix(p_proj[0], W), ndc2pix(p_proj[1], H)};
     int rmin[2], rmax[2];
-    get_rect(point_image, (int)my_radius, gx, gy, rmin, rmax);
-    if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) continue;
+    if (disc_radii) {
+      my_radius = (REAL)disc_radii[idx];
+      rmin[0] = disc_rect[4 * idx]; rmin[1] = disc_rect[4 * idx + 1]; rmax[0] = disc_rect[4 * idx + 2]; rmax[1] = disc_rect[4 * idx + 3];
+    } else {
+      get_rect(point_image, (int)my_radius, gx, gy, rmin, rmax);
+      if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) continue;
+    }
     if (colors_precomp) {
       for (int c = 0; c < 3; ++c) s->rgb[3 * idx + c] = colors_precomp[3 * idx + c];
     } else {
@@ -376,11 +389,15 @@ oracle_state *FN(forward)(int P, int D, int M, const REAL *bg, int W, int H, con
     if (s->radii[idx] <= 0) continue;
     int64_t off = idx == 0 ? 0 : offsets[idx - 1];
     int rmin[2], rmax[2];
-    get_rect(s->means2D + 2 * idx, s->radii[idx], gx, gy, rmin, rmax);
+    if (disc_radii) {
+      rmin[0] = disc_rect[4 * idx]; rmin[1] = disc_rect[4 * idx + 1]; rmax[0] = disc_rect[4 * idx + 2]; rmax[1] = disc_rect[4 * idx + 3];
+    } else {
+      get_rect(s->means2D + 2 * idx, s->radii[idx], gx, gy, rmin, rmax);
+    }
     for (int y = rmin[1]; y < rmax[1]; ++y)
       for (int x = rmin[0]; x < rmax[0]; ++x) {
         inst[off].tile = (uint32_t)(y * gx + x);
-        inst[off].depth = s->depths[idx];
+        inst[off].depth = disc_depth ? (REAL)disc_depth[idx] : s->depths[idx];   /* sort key: the fp32 depth, ties -> index (R4 step 8) */
         inst[off].idx = (uint32_t)idx;
         ++off;
       }
@@ -439,6 +456,38 @@ oracle_state *FN(forward)(int P, int D, int M, const REAL *bg, int W, int H, con
 }
 
 /* accessors for per-stage parity tests */
+oracle_state *FN(forward)(int P, int D, int M, const REAL *bg, int W, int H, const REAL *means3D, const REAL *shs,
+                          const REAL *colors_precomp, const REAL *opacities, const REAL *scales,
+                          REAL scale_modifier, const REAL *rotations, const REAL *cov3D_precomp,
+                          const REAL *viewmatrix, const REAL *projmatrix, const REAL *campos, REAL tan_fovx,
+                          REAL tan_fovy, int flags, REAL *out_color, REAL *out_invdepth, int *radii_out) {
+  return forward_impl(P, D, M, bg, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                      viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, flags, out_color, out_invdepth, radii_out, NULL, NULL, NULL);
+}
+
+/* The same forward under ANOTHER evaluation's discrete decisions (see forward_impl): radii [P], rectangles [P][4] =
+ * (xmin, ymin, xmax, ymax) in tiles, fp32 depths [P] (the sort key). */
+oracle_state *FN(forward_discrete)(int P, int D, int M, const REAL *bg, int W, int H, const REAL *means3D, const REAL *shs,
+                                   const REAL *colors_precomp, const REAL *opacities, const REAL *scales,
+                                   REAL scale_modifier, const REAL *rotations, const REAL *cov3D_precomp,
+                                   const REAL *viewmatrix, const REAL *projmatrix, const REAL *campos, REAL tan_fovx,
+                                   REAL tan_fovy, int flags, REAL *out_color, REAL *out_invdepth, int *radii_out,
+                                   const int *disc_radii, const int *disc_rect, const float *disc_depth) {
+  return forward_impl(P, D, M, bg, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                      viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, flags, out_color, out_invdepth, radii_out, disc_radii,
+                      disc_rect, disc_depth);
+}
+
+/* The discrete decisions of THIS evaluation, in the form forward_discrete takes them. */
+void FN(state_discrete)(const oracle_state *s, int *rect_out /*[P][4]*/, float *depth_out /*[P]*/) {
+  for (int idx = 0; idx < s->P; ++idx) {
+    int rmin[2] = {0, 0}, rmax[2] = {0, 0};
+    if (s->radii[idx] > 0) get_rect(s->means2D + 2 * idx, s->radii[idx], s->tiles_x, s->tiles_y, rmin, rmax);
+    rect_out[4 * idx] = rmin[0]; rect_out[4 * idx + 1] = rmin[1]; rect_out[4 * idx + 2] = rmax[0]; rect_out[4 * idx + 3] = rmax[1];
+    depth_out[idx] = (float)s->depths[idx];
+  }
+}
+
 int64_t FN(num_rendered)(const oracle_state *s) { return s->num_rendered; }
 const REAL *FN(state_depths)(const oracle_state *s) { return s->depths; }
 const REAL *FN(state_means2D)(const oracle_state *s) { return s->means2D; }

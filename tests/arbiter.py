@@ -69,27 +69,42 @@ def _np(x, dtype):
     return np.ascontiguousarray(x.detach().cpu().numpy().astype(dtype))
 
 
-def oracle_view(oracle_mod, g, b, bi, v, H, W, dtype=np.float32, sh_degree=1):
-    """One (item, view) of batch `b` with Gaussian dict `g` ((B,P,...) torch tensors, any device) through the oracle."""
+def oracle_view(oracle_mod, g, b, bi, v, H, W, dtype=np.float32, sh_degree=1, discrete="fp32"):
+    """One (item, view) of batch `b` with Gaussian dict `g` ((B,P,...) torch tensors, any device) through the oracle.  In fp64 this
+    is the ARBITER: continuous arithmetic in fp64 under the fp32 evaluation's discrete decisions (cull, radius, tile rectangle, fp32
+    depth key with index ties -- the reference operator's own integer semantics; oracle.forward(discrete_from=...)).
+    discrete=None: every decision re-taken in fp64 (rounds 1-5)."""
     from unipre3d_amd import head
     t = math.tan(b.fov_deg * math.pi / 360)
     shs = head.concat_sh(g["features_dc"][bi], g["features_rest"][bi])
     return oracle_mod.forward(_np(g["xyz"][bi], dtype), _np(g["opacity"][bi], dtype), _np(b.world_view[bi, v], dtype),
                               _np(b.full_proj[bi, v], dtype), _np(b.camera_center[bi, v], dtype), _np(b.bg, dtype), H, W, t, t,
                               shs=_np(shs, dtype), scales=_np(g["scaling"][bi], dtype), rotations=_np(g["rotation"][bi], dtype),
-                              sh_degree=sh_degree, dtype=dtype)
+                              sh_degree=sh_degree, dtype=dtype, discrete_from=(discrete if np.dtype(dtype) == np.float64 else None))
 
 
 class _OracleRender(torch.autograd.Function):
     """The CPU oracle as a differentiable renderer (one view) for torch autograd on CPU tensors of either dtype."""
 
     @staticmethod
-    def forward(ctx, oracle_mod, means3D, opacities, scales, rotations, shs, view, proj, campos, bg, H, W, t, sh_degree, exact_aa, antialiasing=True):
+    def forward(ctx, oracle_mod, means3D, opacities, scales, rotations, shs, view, proj, campos, bg, H, W, t, sh_degree, exact_aa, antialiasing=True,
+                disc32=None):
+        """disc32 (fp64 evaluations only): the SAME Gaussians as the fp32 chain produces them (fp32 activations of the fp32 head output:
+        (means3D, opacities, scales, rotations, shs) float32 tensors).  The fp32 restatement of those decides cull / radius / rectangle /
+        depth order for this fp64 evaluation -- the reference operator's integer semantics."""
         dt = np.float32 if means3D.dtype == torch.float32 else np.float64
         n = lambda x: np.ascontiguousarray(x.detach().numpy())
+        d32 = None
+        if dt == np.float64 and disc32 is not None:
+            f = np.float32
+            d32 = oracle_mod.forward(n(disc32[0]), n(disc32[1]), n(view).astype(f), n(proj).astype(f), n(campos).astype(f), n(bg).astype(f), H, W, t, t,
+                                     shs=n(disc32[4]), scales=n(disc32[2]), rotations=n(disc32[3]), sh_degree=sh_degree, dtype=f,
+                                     exact_aa_grad=exact_aa, antialiasing=antialiasing)
         r = oracle_mod.forward(n(means3D), n(opacities), n(view).astype(dt), n(proj).astype(dt), n(campos).astype(dt), n(bg).astype(dt),
                                H, W, t, t, shs=n(shs), scales=n(scales), rotations=n(rotations), sh_degree=sh_degree, dtype=dt,
-                               exact_aa_grad=exact_aa, antialiasing=antialiasing)
+                               exact_aa_grad=exact_aa, antialiasing=antialiasing, discrete_from=d32)
+        if d32 is not None:
+            d32.close()
         ctx.r, ctx.oracle_mod, ctx.tdt = r, oracle_mod, means3D.dtype
         return torch.from_numpy(r.color.copy())
 
@@ -98,11 +113,23 @@ class _OracleRender(torch.autograd.Function):
         go = ctx.oracle_mod.backward(ctx.r, np.ascontiguousarray(gcol.numpy()))
         ctx.r.close()
         f = lambda k: torch.from_numpy(np.ascontiguousarray(go[k])).to(ctx.tdt)
-        return (None, f("means3D"), f("opacities"), f("scales"), f("rotations"), f("shs")) + (None,) * 10
+        return (None, f("means3D"), f("opacities"), f("scales"), f("rotations"), f("shs")) + (None,) * 11
+
+
+def _activate(b, raw, center, sh_degree):
+    """Gaussians of ONE item from its raw head output (1,C,P) in raw's dtype, through the reference's activations (head.py, G2)."""
+    from unipre3d_amd import head
+    if b.level == "object":
+        g = head.process_object_output(raw, center, b.offset_scale, sh_degree)
+        return {k: x[0] for k, x in g.items()}
+    C, P = raw.shape[1], raw.shape[2]
+    flat = raw.permute(0, 2, 1).reshape(P, C)
+    lists = head.process_scene_output(flat, center.reshape(P, 3), torch.zeros(P, 1, dtype=torch.long), b.offset_scale, sh_degree)
+    return {k: x[0] for k, x in lists.items()}
 
 
 def head_grad_arbiter(oracle_mod, b, bi, v, H, W, n_views_total, loss_kind, dtype=np.float64, sh_degree=1,
-                      non_bg_rate=4.0, bg_rate=1.0, exact_aa_grad=False, loss_scale=1.0, antialiasing=True):
+                      non_bg_rate=4.0, bg_rate=1.0, exact_aa_grad=False, loss_scale=1.0, antialiasing=True, discrete="fp32"):
     """d loss / d raw[bi] ((C, P), the reference's (B, 23, N) layout) where loss = render loss over ALL n_views_total views'
     pixels but only view (bi, v) differs from its target -- i.e. the per-view contribution the fused kernels can be made to
     isolate by setting gt = rendered for every other view.  Returns (gradient (C,P) ndarray, loss value, image (3,H,W))."""
@@ -110,19 +137,19 @@ def head_grad_arbiter(oracle_mod, b, bi, v, H, W, n_views_total, loss_kind, dtyp
     tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
     raw = b.raw[bi:bi + 1].detach().cpu().to(tdt).clone().requires_grad_(True)
     center = b.center[bi:bi + 1].detach().cpu().to(tdt)
-    if b.level == "object":
-        g = head.process_object_output(raw, center, b.offset_scale, sh_degree)
-        g = {k: x[0] for k, x in g.items()}
-    else:
-        C, P = raw.shape[1], raw.shape[2]
-        flat = raw.permute(0, 2, 1).reshape(P, C)
-        lists = head.process_scene_output(flat, center.reshape(P, 3), torch.zeros(P, 1, dtype=torch.long), b.offset_scale, sh_degree)
-        g = {k: x[0] for k, x in lists.items()}
+    g = _activate(b, raw, center, sh_degree)
     t = math.tan(b.fov_deg * math.pi / 360)
     shs = head.concat_sh(g["features_dc"], g["features_rest"])
+    disc32 = None
+    if tdt == torch.float64 and discrete == "fp32":
+        # the arbiter: fp64 arithmetic under the discrete decisions (cull, radius, rectangle, fp32 depth order with index ties) of the
+        # fp32 chain -- fp32 activations of the fp32 head output through the fp32 restatement, i.e. what the reference's operator sees
+        with torch.no_grad():
+            g32 = _activate(b, b.raw[bi:bi + 1].detach().cpu().float(), b.center[bi:bi + 1].detach().cpu().float(), sh_degree)
+            disc32 = (g32["xyz"], g32["opacity"], g32["scaling"], g32["rotation"], head.concat_sh(g32["features_dc"], g32["features_rest"]))
     c = lambda x: x.detach().cpu()
     img = _OracleRender.apply(oracle_mod, g["xyz"], g["opacity"], g["scaling"], g["rotation"], shs, c(b.world_view[bi, v]),
-                              c(b.full_proj[bi, v]), c(b.camera_center[bi, v]), c(b.bg), H, W, t, sh_degree, exact_aa_grad, antialiasing)
+                              c(b.full_proj[bi, v]), c(b.camera_center[bi, v]), c(b.bg), H, W, t, sh_degree, exact_aa_grad, antialiasing, disc32)
     gt = c(b.gt[bi, v]).to(tdt)
     white = bool(b.bg[0].item() > 0.5) if loss_kind == "focal_l2" else False
     # the loss of this one view, re-normalised to the whole batch's pixel count (the other views contribute exact zeros)
@@ -134,7 +161,8 @@ def head_grad_arbiter(oracle_mod, b, bi, v, H, W, n_views_total, loss_kind, dtyp
     return raw.grad[0].numpy().copy() / loss_scale, float(loss.item()), img.detach().numpy().copy()
 
 
-def head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, dtype=np.float64, sh_degree=1, input_images=0, loss_scale=1.0, antialiasing=True):
+def head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, dtype=np.float64, sh_degree=1, input_images=0, loss_scale=1.0, antialiasing=True,
+                          discrete="fp32"):
     """d loss / d raw for the WHOLE batch ((B, C, P)): the per-view arbiters summed over every item's views (small shapes only:
     one oracle render per view).  Also returns the loss value."""
     B, V = b.raw.shape[0], b.world_view.shape[1] - input_images
@@ -142,7 +170,8 @@ def head_grad_arbiter_all(oracle_mod, b, H, W, loss_kind, dtype=np.float64, sh_d
     for bi in range(B):
         acc = None
         for v in range(input_images, input_images + V):
-            g, l, _ = head_grad_arbiter(oracle_mod, b, bi, v, H, W, B * V, loss_kind, dtype, sh_degree, loss_scale=loss_scale, antialiasing=antialiasing)
+            g, l, _ = head_grad_arbiter(oracle_mod, b, bi, v, H, W, B * V, loss_kind, dtype, sh_degree, loss_scale=loss_scale, antialiasing=antialiasing,
+                                        discrete=discrete)
             acc = g if acc is None else acc + g
             loss += l
         out.append(acc)

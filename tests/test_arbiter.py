@@ -17,7 +17,8 @@ def test_head_grad_arbiter_matches_autograd_of_the_whole_chain(oracle_mod, level
     B, P, V, H, W = 2, 40, 3, 40, 56
     b = synthetic.make_batch(B, P, V, H, W, level=level, seed=17)
     bi, v = 1, 2
-    ga, la, img = head_grad_arbiter(oracle_mod, b, bi, v, H, W, B * V, kind, np.float64, exact_aa_grad=True)
+    # (discrete=None: the torch restatement decides cull / radius / order in fp64 itself, so the comparison is like for like)
+    ga, la, img = head_grad_arbiter(oracle_mod, b, bi, v, H, W, B * V, kind, np.float64, exact_aa_grad=True, discrete=None)
     raw = b.raw[bi:bi + 1].double().clone().requires_grad_(True)
     if level == "object":
         g = {k: x[0] for k, x in head.process_object_output(raw, b.center[bi:bi + 1].double(), b.offset_scale, 1).items()}

@@ -33,7 +33,7 @@ def test_fuzz_forward_backward_vs_oracle(oracle_mod, P, H, W, level, compact, de
     dcol, dinv = cotangents(H, W, seed=seed)
     color, invd, radii, g = _run_gpu(sc, dcol, dinv)
     r32 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc))
-    r64 = oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
+    r64 = oracle_mod.forward(dtype=np.float64, discrete_from="fp32", **to_numpy(sc))
     assert np.array_equal(radii, r32.radii)      # integer output: bit-exact against the fp32 restatement
     assert_parity(color, r32.color, r64.color, "color")
     assert_parity(invd, r32.invdepth, r64.invdepth, "invd")

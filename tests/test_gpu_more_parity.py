@@ -37,7 +37,7 @@ def _oracle(oracle_mod, s, v, H, W, t, deg, dtype, **kw):
     for k in kw.pop("drop", ()):
         args.pop(k)
     return oracle_mod.forward(n(s["means3D"]), n(s["opacities"]), n(b.world_view[0, v]), n(b.full_proj[0, v]), n(b.camera_center[0, v]), n(b.bg), H, W,
-                              t, t, sh_degree=deg, dtype=dtype, **args, **kw)
+                              t, t, sh_degree=deg, dtype=dtype, discrete_from=("fp32" if np.dtype(dtype) == np.float64 else None), **args, **kw)
 
 
 @pytest.mark.parametrize("sizes,level,deg,mod,aa,ragged", [

@@ -52,7 +52,7 @@ def test_forward_backward_vs_oracle(oracle_mod, P, H, W, level, compact, deg, se
     for k in DIFF_KEYS + ("means2D",):
         assert rel_l2(g[k].reshape(go[k].shape), go[k]) < TOL, k
     # fp64 arbiter: the GPU is as close to the fp64 result as the fp32 oracle is (within 10x)
-    r64 = oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
+    r64 = oracle_mod.forward(dtype=np.float64, discrete_from="fp32", **to_numpy(sc))
     assert rel_l2(color, r64.color) < max(10 * rel_l2(r.color, r64.color), 1e-6)
 
 
@@ -102,7 +102,7 @@ def test_radix_sort_far_depths(oracle_mod, F, P):
     sc["means3D"][200:230] = sc["means3D"][200]                   # depth ties resolve by index on this path too
     dcol, dinv = cotangents(64, 80)
     color, invd, radii, g = _run_gpu(sc, dcol, dinv)
-    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
+    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, discrete_from="fp32", **to_numpy(sc))
     zv = (np.c_[to_numpy(sc)["means3D"].astype(np.float64), np.ones(P)] @ V2.numpy())[:, 2]
     assert zv[r.radii > 0].min() > 0.2 * F and zv[r.radii > 0].max() > 4.0 * zv[r.radii > 0].min()
     assert np.array_equal(radii, r.radii)
@@ -132,7 +132,7 @@ def test_large_P_sort_dense_depth_bucket(oracle_mod, n_dense, spread):
     sc["means3D"][idx] += ((target - z[idx])[:, None] * fwd[None, :]).float()
     dcol, dinv = cotangents(H, W)
     color, invd, radii, gg = _run_gpu(sc, dcol, dinv)
-    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
+    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, discrete_from="fp32", **to_numpy(sc))
     assert np.array_equal(radii, r.radii)
     assert_parity(color, r.color, r64.color, "color")
     go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
@@ -155,7 +155,7 @@ def test_block_sort_clustered_depths(oracle_mod, n_tied):
     sc["opacities"][idx] = torch.linspace(0.05, 0.6, n_tied)[:, None]
     dcol, dinv = cotangents(H, W)
     color, invd, radii, gg = _run_gpu(sc, dcol, dinv)
-    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
+    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, discrete_from="fp32", **to_numpy(sc))
     assert np.array_equal(radii, r.radii)
     assert_parity(color, r.color, r64.color, "color")
     go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
@@ -230,7 +230,7 @@ def test_non_saturating_pixels_scan_whole_list(oracle_mod):
         sc["opacities"] = sc["opacities"] * 0.02
         dcol, dinv = cotangents(64, 64)
         color, invd, radii, g = _run_gpu(sc, dcol, dinv)
-        r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
+        r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, discrete_from="fp32", **to_numpy(sc))
         go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
         assert int(r.n_contrib.max()) > 256
         assert np.array_equal(radii, r.radii)
@@ -253,7 +253,7 @@ def test_truly_compact_splats_operator_level(oracle_mod, P, H, W, level):
     sc["rotations"] = torch.nn.functional.normalize(torch.randn(P, 4, generator=g), dim=-1)
     dcol, dinv = cotangents(H, W)
     color, invd, radii, gr = _run_gpu(sc, dcol, dinv)
-    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
+    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, discrete_from="fp32", **to_numpy(sc))
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     vis = int((r.radii > 0).sum())
     assert vis > P // 10 and r.num_rendered < 0.25 * vis * tiles         # genuinely sparse binning
@@ -335,7 +335,7 @@ def test_loop_variants_high_opacity(oracle_mod, P, fade, every):
     sc["opacities"][::every] = torch.linspace(0.981, 1.0, len(sc["opacities"][::every]))[:, None]
     dcol, dinv = cotangents(H, W)
     color, invd, radii, g = _run_gpu(sc, dcol, dinv)
-    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, **to_numpy(sc))
+    r, r64 = oracle_mod.forward(dtype=np.float32, **to_numpy(sc)), oracle_mod.forward(dtype=np.float64, discrete_from="fp32", **to_numpy(sc))
     go, go64 = oracle_mod.backward(r, dcol.numpy(), dinv.numpy()), oracle_mod.backward(r64, dcol.numpy(), dinv.numpy())
     assert np.array_equal(radii, r.radii)
     assert_parity(color, r.color, r64.color, "color")
