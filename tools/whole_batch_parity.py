@@ -1,7 +1,7 @@
 """Whole-batch parity of the fused step at a BASELINE config's full per-GPU shape: loss and d loss / d head_out of EVERY object and view (what bench.py
 times) against the CPU oracle chained through the reference's activations and loss, fp32 and fp64, under the one parity rule
 (tests/arbiter.py::assert_parity).  The GPU tests sample 1 - 3 (item, view) pairs per scene-level config because the oracle needs minutes for a
-whole batch there; this tool spends them once per round and its log is committed (profiles/r05/whole_batch_parity.log).
+whole batch there; this tool spends them once per round and its log is committed (profiles/r06/whole_batch_parity.log).
 usage: python tools/whole_batch_parity.py C4 [C5 ...]"""
 import os, sys, time
 import numpy as np, torch
@@ -33,7 +33,7 @@ for name in sys.argv[1:] or ["C4"]:
     e64, e32, gap = arbiter.parity_errors(hg, a32, a64)
     ok = arbiter.parity_ok(hg, a32, a64)
     per_item = [rel_l2(hg[i], a64[i]) for i in range(B)]
-    print(f"{name}: {B} x {V} views, P = {P}, {H}x{W}, loss {kind}: loss hip {loss.item():.8f} f64 {l64:.8f} (rel {abs(loss.item() - l64) / abs(l64):.1e}); "
-          f"d(head_out) whole batch |hip-f64| {e64:.2e} |hip-f32| {e32:.2e} fp32 restatement's own |f32-f64| {gap:.2e} -> parity rule "
-          f"{'PASS' if ok else 'FAIL'}{'' if e64 <= arbiter.TOL else ' (through the fp32-gap branch)'}; per object {[f'{x:.2e}' for x in per_item]}; "
-          f"oracle time {time.time() - t0:.0f} s", flush=True)
+    verdict = "PASS (within 1e-4 of the arbiter)" if e64 <= arbiter.TOL else ("PASS (through the fp32-gap branch)" if ok else "FAIL")
+    print(f"{name}: {B} x {V} views, P = {P}, {H}x{W}, loss {kind}: loss hip {loss.item():.8f} arbiter {l64:.8f} (rel {abs(loss.item() - l64) / abs(l64):.1e}); "
+          f"d(head_out) whole batch |hip-f64| {e64:.2e} |hip-f32| {e32:.2e} fp32 restatement's own |f32-f64| {gap:.2e} -> parity rule {verdict}; "
+          f"per object {[f'{x:.2e}' for x in per_item]}; oracle time {time.time() - t0:.0f} s", flush=True)
