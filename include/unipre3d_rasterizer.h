@@ -54,6 +54,7 @@ extern "C" {
                                     Gaussian) pair: most of the step's projection-kernel traffic at scene level, one launch per call of
                                     the per-view operator route */
 
+#define U3D_SPARSE_BWD_MIN_P 4096  /* U3D_FLAG_SPARSE_BWD is honoured for sets of MORE than this many Gaussians (the library's LDS-sort limit) */
 #define U3D_FLAG_SPARSE_BWD 64   /* u3d_render_loss_step_forward / _backward (scene-level head, P > 4096 only; ignored otherwise): the
                                     caller hands the forward half the gradient buffer `d_head_out` it will pass to the backward half.
                                     The forward half zero-fills it (extra workgroups of the gradient reduction, off the critical path)

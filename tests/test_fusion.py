@@ -100,3 +100,43 @@ def test_feature_fusion_transformer_sized():
             if cp[b, n, 2] == zb[(u[b, n], v[b, n])]:
                 exp[b, n] = feat[b, :, u[b, n], v[b, n]].numpy()
     assert np.array_equal(mapped, exp) and (np.abs(exp).sum(-1) > 0).mean() > 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,C", [(16, 16, 5), (9, 7, 11), (128, 128, 40)])
+def test_gather_form_backward_writes_every_element_once_and_adds_tied_points(H, W, C):
+    """ABI 2 backward (gather form): the kernel writes EVERY element of the (B,C,H,W) gradient (autograd hands it uninitialised memory), points that
+    tie for a pixel at the same depth all contribute (fusion/feat_fusion.py:117-131), H*W need not be a multiple of 4, and the result equals the
+    numpy restatement pinned to G7 (oracle/fusion_oracle.py::mapped_grad)."""
+    from oracle import fusion_oracle as fo
+    from unipre3d_amd import _lib, fusion
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(H * 131 + W)
+    B, N = 3, 60
+    cp = torch.cat([torch.randn(B, N, 2, generator=gen) * 0.4, 1.0 + torch.rand(B, N, 1, generator=gen), torch.ones(B, N, 1)], dim=-1)
+    cp[:, 10] = cp[:, 3]; cp[:, 40] = cp[:, 3]            # three points on one pixel at the SAME depth: all three are winners
+    cp[:, 20, :2] = cp[:, 5, :2] * (cp[:, 20, 2:3] / cp[:, 5, 2:3])   # same pixel, farther: occluded
+    f = float(min(H, W))
+    feat = torch.randn(B, C, H, W, generator=gen).to(dev).requires_grad_(True)
+    mapped, sel = fusion._ZBufferGather.apply(cp.to(dev), feat, f, f, H / 2.0, W / 2.0)
+    w = torch.randn(B, N, C, generator=gen)
+    # poison the caching allocator's free blocks so that an element the kernel skipped would show
+    junk = torch.full((B, C, H, W), float("nan"), device=dev); del junk
+    (mapped * w.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    s = sel.cpu().numpy()
+    assert (s[:, 3] >= 0).all() and (s[:, 3] == s[:, 10]).all() and (s[:, 3] == s[:, 40]).all()
+    ref = fo.mapped_grad(w.numpy(), s, B, C, H, W)
+    got = feat.grad.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+    untied = np.ones_like(ref, dtype=bool)
+    for b in range(B):
+        untied[b, :, s[b, 3] // W, s[b, 3] % W] = False
+    assert np.array_equal(got[untied], ref[untied])         # single winners: copies, bit-exact
+    # N = 0: an all-zero gradient
+    gz = torch.full((1, 2, 4, 4), float("nan"), device=dev)
+    assert fusion.load().u3d_zbuffer_fusion_backward(1, 0, 2, 4, 4, _lib.ptr(None), _lib.ptr(None), _lib.ptr(None), _lib.ptr(gz),
+                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    assert not gz.any()

@@ -330,3 +330,41 @@ def test_render_view_entry_points_equal_the_operator_entry_points(oracle_mod):
     assert torch.equal(c0, c1) and torch.equal(r0, r1)
     assert lib.u3d_render_view_forward(ctypes.byref(plan.desc), p(bd.bg), p(xyz), p(dc), p(None), p(op), p(sc), p(rot), *cams, p(cb), p(rb), p(vb),
                                        p(sb[0]), p(sb[1]), p(sb[2]), stream) == 1          # M = 4 without features_rest: invalid argument
+
+
+def test_general_loop_variant_on_a_plain_scene_agrees_with_the_plain_variant(tmp_path):
+    """since alpha_run the tile kernels' two loop variants are not bit-identical (PLAIN: alpha from the forward-differenced
+    recurrence; general: exp2(pw) per pixel).  A build that sends EVERY tile through the general variant (-DU3D_FORCE_GENERAL) must agree with
+    the product build on a scene whose tiles all qualify for PLAIN: images to 1e-5, gradients to 1e-4 (a 1/255 threshold decided differently
+    by a forward and its backward would desynchronise stop_pos from the recomputed alphas and show as an O(1) gradient error), radii equal --
+    in the single-pass kernel, the two-pass kernels (which hand the variant over through U3D_TILE_PLAIN_BIT) and the operator path."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc, var = os.path.join(root, "unipre3d_amd", "csrc"), os.path.join(root, "unipre3d_amd", "lib_general")
+    lib = os.path.join(var, "libunipre3d_rasterizer.so")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs):
+        res = subprocess.run(["make", "-C", csrc, "-j4", "LIBDIR=../lib_general", "EXTRA=-DU3D_FORCE_GENERAL", "../lib_general/libunipre3d_rasterizer.so"],
+                             capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
+    shutil.copy2(os.path.join(root, "unipre3d_amd", "lib", "_u3d_torch.so"), os.path.join(var, "_u3d_torch.so"))   # (rpath $ORIGIN: binds the variant)
+    outs = {}
+    for name, dirname in (("plain", "lib"), ("general", "lib_general")):
+        path = str(tmp_path / f"{name}.npz")
+        res = subprocess.run([sys.executable, os.path.join(root, "tests", "variant_dump.py"), path], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, U3D_LIB_DIRNAME=dirname))
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs[name] = np.load(path)
+    a, g = outs["plain"], outs["general"]
+    for route in ("single", "two"):
+        assert np.array_equal(a[route + "_radii"], g[route + "_radii"])
+        assert rel_l2(g[route + "_img"], a[route + "_img"]) < 1e-5 and abs(g[route + "_loss"] - a[route + "_loss"]) < 1e-5 * abs(a[route + "_loss"])
+        assert rel_l2(g[route + "_grad"], a[route + "_grad"]) < 1e-4, (route, rel_l2(g[route + "_grad"], a[route + "_grad"]))
+    assert np.array_equal(a["single_img"], a["two_img"]) and np.array_equal(g["single_img"], g["two_img"])     # within a build the routes share the forward
+    assert rel_l2(g["op_img"], a["op_img"]) < 1e-5
+    for k in ("xyz", "opacity", "scaling", "rotation"):
+        assert rel_l2(g["op_d" + k], a["op_d" + k]) < 1e-4, (k, rel_l2(g["op_d" + k], a["op_d" + k]))
+    assert not np.array_equal(a["single_img"], g["single_img"]), "the forced build took the same variant: U3D_FORCE_GENERAL did not reach the kernel"

@@ -15,6 +15,7 @@
 #define U3D_TILE_PLAIN_BIT 0x80000000u   /* tile_last: the forward ran the loop variant without clamp / pw test */
 #define U3D_NACC 10         // mean2D.xy, conic(a, b/2, c), opacity, rgb, invdepth
 #define U3D_LDS_SORT_MAX 4096  // largest per-view P sorted by one workgroup in LDS
+static_assert(U3D_LDS_SORT_MAX == U3D_SPARSE_BWD_MIN_P, "the public header's sparse-backward threshold is this limit (the torch binding sizes its buffers by it)");
 // keys per workgroup and radix pass (P > U3D_LDS_SORT_MAX): small tiles keep more workgroups in flight (the passes are
 // latency-bound), large tiles keep the per-block offset scan short
 // radix workgroup shapes (threads x keys per thread and pass), measured sweep on C4 (40 k keys/view) and C5 (200 k):
@@ -337,6 +338,27 @@ __device__ __forceinline__ float u3d_quad_sum(float v) {
                "s_nop 1"
                : "+v"(v));
   return v;
+}
+
+// Minimum of a 32-bit value over the wave, wave-uniform (SGPR): four DPP steps leave every lane with its 16-lane row's minimum, the four row
+// results are read into SGPRs and combined on the scalar unit (no LDS round trips).
+template <int CTRL>
+__device__ __forceinline__ uint32_t u3d_dpp_min_step(uint32_t v) {
+  const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+  return o < v ? o : v;
+}
+__device__ __forceinline__ uint32_t u3d_wave_min_u32(uint32_t v) {
+  v = u3d_dpp_min_step<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = u3d_dpp_min_step<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = u3d_dpp_min_step<0x141>(v);   // row_half_mirror
+  v = u3d_dpp_min_step<0x140>(v);   // row_mirror
+  uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+#pragma unroll
+  for (int q = 1; q < 4; ++q) {
+    const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)v, q * 16);
+    r = u < r ? u : r;
+  }
+  return r;
 }
 
 __device__ __forceinline__ uint32_t u3d_lane_id() {

@@ -19,19 +19,24 @@ __device__ __forceinline__ int project(const float* __restrict__ cp, int H, int 
   return py * H + px;
 }
 
+// Winner table (ABI 2): one 64-bit word per pixel, (depth bits << 32) | point index, indexed by sel = px*W + py.  One atomic min gives the
+// z-test (high half: depths are >= 0, so their bits order like unsigned integers) AND, in the low half, the smallest index among the points
+// that tie at the minimum -- the pixel's "first winner", which the backward gathers from.  Empty pixels keep the 0xFF fill.
 __global__ void zbuf_min_kernel(int N, int H, int W, int total, float fx, float fy, float cx, float cy,
-                                const float* __restrict__ camera_points, uint32_t* __restrict__ zbuf) {
+                                const float* __restrict__ camera_points, unsigned long long* __restrict__ zbuf) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int b = t / N;
   int px, py; float d;
   const int key = project(camera_points + (size_t)t * 4, H, W, fx, fy, cx, cy, px, py, d);
-  if (key >= 0) atomicMin(&zbuf[(size_t)b * H * W + key], __float_as_uint(d == 0.f ? 0.f : d));   // d >= 0: bits are ordered
+  if (key >= 0)
+    atomicMin(&zbuf[(size_t)b * H * W + (size_t)px * W + py],
+              ((unsigned long long)__float_as_uint(d == 0.f ? 0.f : d) << 32) | (unsigned)(t - b * N));
 }
 
 __global__ void gather_kernel(int N, int C, int H, int W, int total, float fx, float fy, float cx, float cy,
                               const float* __restrict__ camera_points, const float* __restrict__ feat,
-                              const uint32_t* __restrict__ zbuf, float* __restrict__ mapped, int32_t* __restrict__ sel) {
+                              const unsigned long long* __restrict__ zbuf, float* __restrict__ mapped, int32_t* __restrict__ sel) {
   // one wave per point: lanes stride over the C channels (mapped rows are contiguous)
   const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -39,53 +44,126 @@ __global__ void gather_kernel(int N, int C, int H, int W, int total, float fx, f
   const int b = t / N;
   int px = 0, py = 0; float d;
   const int key = project(camera_points + (size_t)t * 4, H, W, fx, fy, cx, cy, px, py, d);
-  const bool win = key >= 0 && zbuf[(size_t)b * H * W + key] == __float_as_uint(d == 0.f ? 0.f : d);
+  const bool win = key >= 0 && (uint32_t)(zbuf[(size_t)b * H * W + (size_t)px * W + py] >> 32) == __float_as_uint(d == 0.f ? 0.f : d);
   if (lane == 0) sel[t] = win ? px * W + py : -1;
   float* o = mapped + (size_t)t * C;
   const float* f = feat + (size_t)b * C * H * W + (size_t)px * W + py;
   for (int c = lane; c < C; c += 64) o[c] = win ? f[(size_t)c * H * W] : 0.f;
 }
 
-__global__ void scatter_grad_kernel(int N, int C, int H, int W, int total, const float* __restrict__ grad_mapped,
-                                    const int32_t* __restrict__ sel, float* __restrict__ grad_feat) {
+// Backward in GATHER form: every element of the (B,C,H,W) gradient is written exactly once --
+// grad_feat[b][c][s] = grad_mapped[b][first winner of pixel s][c], or 0 -- instead of a zero-fill of the 805 MB followed by a scatter.
+// A thread owns 4 consecutive pixels of KC channel planes: the winner words are read once (the table is B*H*W*8 bytes, L2-resident),
+// the stores are 16 B per lane = 1 KB contiguous per wave and plane.  Fewer than 1 % of the pixels have a winner at the reference's sizes.
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // (a clang vector: __builtin_nontemporal_store takes no HIP float4 struct)
+
+template <int KC>
+__global__ __launch_bounds__(256) void grad_dense4_kernel(int N, int C, int HW, const float* __restrict__ grad_mapped,
+                                                          const unsigned long long* __restrict__ zbuf, float* __restrict__ grad_feat) {
+  const int HW4 = HW >> 2;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= HW4) return;
+  const int c0 = blockIdx.y * KC, b = blockIdx.z;
+  const ulonglong2* zp = reinterpret_cast<const ulonglong2*>(zbuf + (size_t)b * HW) + 2 * (size_t)q;
+  const ulonglong2 z01 = zp[0], z23 = zp[1];
+  const uint32_t w0 = (uint32_t)z01.x, w1 = (uint32_t)z01.y, w2 = (uint32_t)z23.x, w3 = (uint32_t)z23.y;
+  f32x4* o = reinterpret_cast<f32x4*>(grad_feat + ((size_t)b * C + c0) * HW) + q;
+  const int kc = C - c0 < KC ? C - c0 : KC;
+  if ((w0 & w1 & w2 & w3) == 0xffffffffu) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (k < kc) __builtin_nontemporal_store(z, o + (size_t)k * HW4);
+  } else {
+    const float* g = grad_mapped + (size_t)b * N * C + c0;
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (k < kc) {
+        f32x4 v;
+        v.x = w0 != 0xffffffffu ? g[(size_t)w0 * C + k] : 0.f;
+        v.y = w1 != 0xffffffffu ? g[(size_t)w1 * C + k] : 0.f;
+        v.z = w2 != 0xffffffffu ? g[(size_t)w2 * C + k] : 0.f;
+        v.w = w3 != 0xffffffffu ? g[(size_t)w3 * C + k] : 0.f;
+        __builtin_nontemporal_store(v, o + (size_t)k * HW4);
+      }
+  }
+}
+
+// H*W not a multiple of 4: one pixel per thread
+template <int KC>
+__global__ __launch_bounds__(256) void grad_dense1_kernel(int N, int C, int HW, const float* __restrict__ grad_mapped,
+                                                          const unsigned long long* __restrict__ zbuf, float* __restrict__ grad_feat) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= HW) return;
+  const int c0 = blockIdx.y * KC, b = blockIdx.z;
+  const uint32_t w = (uint32_t)zbuf[(size_t)b * HW + q];
+  float* o = grad_feat + ((size_t)b * C + c0) * HW + q;
+  const float* g = grad_mapped + (size_t)b * N * C + c0;
+  const int kc = C - c0 < KC ? C - c0 : KC;
+  for (int k = 0; k < kc; ++k) o[(size_t)k * HW] = w != 0xffffffffu ? g[(size_t)w * C + k] : 0.f;
+}
+
+// Points that TIE with their pixel's first winner (same depth bits, larger index) add their rows afterwards: the reference keeps all tied
+// points (fusion/feat_fusion.py:117-131).  One wave per point; nearly every wave leaves at once.
+__global__ void tie_add_kernel(int N, int C, int HW, int total, const float* __restrict__ grad_mapped, const int32_t* __restrict__ sel,
+                               const unsigned long long* __restrict__ zbuf, float* __restrict__ grad_feat) {
   const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (t >= total) return;
   const int s = sel[t];
   if (s < 0) return;
   const int b = t / N;
-  float* g = grad_feat + (size_t)b * C * H * W + s;
+  if ((uint32_t)zbuf[(size_t)b * HW + s] == (uint32_t)(t - b * N)) return;
+  float* g = grad_feat + (size_t)b * C * HW + s;
   const float* go = grad_mapped + (size_t)t * C;
-  for (int c = lane; c < C; c += 64) unsafeAtomicAdd(&g[(size_t)c * H * W], go[c]);
+  for (int c = lane; c < C; c += 64) unsafeAtomicAdd(&g[(size_t)c * HW], go[c]);
 }
 
 }  // namespace
 
 extern "C" {
 
+int u3d_fusion_abi_version(void) { return U3D_FUSION_ABI_VERSION; }
+
 int u3d_zbuffer_fusion_forward(int B, int N, int C, int H, int W, float fx, float fy, float cx, float cy,
                                const float* camera_points, const float* image_features, float* mapped, int32_t* sel,
-                               uint32_t* zbuf, void* stream) {
+                               uint64_t* zbuf, void* stream) {
   if (B < 0 || N < 0 || C < 0 || H <= 0 || W <= 0) return 1;
   if (B == 0 || N == 0) return 0;
   if (!camera_points || !image_features || !mapped || !sel || !zbuf) return 1;
   hipStream_t s = (hipStream_t)stream;
   const int total = B * N;
-  (void)hipMemsetAsync(zbuf, 0xFF, sizeof(uint32_t) * (size_t)B * H * W, s);
-  hipLaunchKernelGGL(zbuf_min_kernel, dim3((total + 255) / 256), dim3(256), 0, s, N, H, W, total, fx, fy, cx, cy, camera_points, zbuf);
+  (void)hipMemsetAsync(zbuf, 0xFF, sizeof(uint64_t) * (size_t)B * H * W, s);
+  hipLaunchKernelGGL(zbuf_min_kernel, dim3((total + 255) / 256), dim3(256), 0, s, N, H, W, total, fx, fy, cx, cy, camera_points,
+                     (unsigned long long*)zbuf);
   hipLaunchKernelGGL(gather_kernel, dim3((total + 3) / 4), dim3(256), 0, s, N, C, H, W, total, fx, fy, cx, cy, camera_points,
-                     image_features, zbuf, mapped, sel);
+                     image_features, (const unsigned long long*)zbuf, mapped, sel);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
-int u3d_zbuffer_fusion_backward(int B, int N, int C, int H, int W, const float* grad_mapped, const int32_t* sel,
+int u3d_zbuffer_fusion_backward(int B, int N, int C, int H, int W, const float* grad_mapped, const int32_t* sel, const uint64_t* zbuf,
                                 float* grad_features, void* stream) {
   if (B < 0 || N < 0 || C < 0 || H <= 0 || W <= 0) return 1;
-  if (B == 0 || N == 0 || C == 0) return 0;
-  if (!grad_mapped || !sel || !grad_features) return 1;
+  if (B == 0 || C == 0) return 0;
+  if (!grad_features) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const int HW = H * W;
+  if (N == 0) {   // no points: the gradient is all zeros
+    (void)hipMemsetAsync(grad_features, 0, sizeof(float) * (size_t)B * C * HW, s);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+  }
+  if (!grad_mapped || !sel || !zbuf) return 1;
+  if (B > 65535 || (C + 7) / 8 > 65535) return 2;
+  constexpr int KC = 8;
+  const unsigned long long* z = (const unsigned long long*)zbuf;
+  if ((HW & 3) == 0)
+    hipLaunchKernelGGL(grad_dense4_kernel<KC>, dim3(((HW >> 2) + 255) / 256, (C + KC - 1) / KC, B), dim3(256), 0, s, N, C, HW, grad_mapped, z,
+                       grad_features);
+  else
+    hipLaunchKernelGGL(grad_dense1_kernel<KC>, dim3((HW + 255) / 256, (C + KC - 1) / KC, B), dim3(256), 0, s, N, C, HW, grad_mapped, z,
+                       grad_features);
   const int total = B * N;
-  hipLaunchKernelGGL(scatter_grad_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, N, C, H, W, total, grad_mapped, sel,
-                     grad_features);
+  hipLaunchKernelGGL(tie_add_kernel, dim3((total + 3) / 4), dim3(256), 0, s, N, C, HW, total, grad_mapped, sel, z, grad_features);
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "unipre3d_pointops.h"
 
@@ -59,6 +60,7 @@ __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, f
   const float dx = bx - ax, dy = by - ay, dz = bz - az;
   return sum3<CM>(dx, dx, dy, dy, dz, dz);
 }
+bool g_interp_lds = getenv("U3D_INTERP_GLOBAL") == nullptr;   // (experiment switch: U3D_INTERP_GLOBAL=1 keeps round 5's global-gather kernel)
 int g_contraction = U3D_PO_FMA_LLVM;   // host: mode of the launches that follow (process-wide, like a build flag of the reference)
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
@@ -319,28 +321,54 @@ __global__ __launch_bounds__(256) void group_points_grad_lds_kernel(int c, int n
     // Ball-query index sets pad every group with copies of its first hit: runs of EQUAL CONSECUTIVE destinations, which would meet in one LDS
     // word (the compare-and-swap collapses there).  A wave that holds such a run sums it first -- segmented inclusive scan over the run, the
     // run's last lane keeps the total -- and only the tails update LDS.  Waves without adjacent duplicates (gather, three_nn-style indices)
-    // skip this.
+    // skip this.  Round 6: the scan runs on DPP (row_shr 1/2/4/8 inside the 16-lane rows, then the two GFX9 row broadcasts) instead of
+    // 6 ds_bpermute round trips per channel, the run structure comes from one ballot (run start = highest head bit at or below the lane), and
+    // the per-step conditions are 0/1 multipliers of a v_fmac_f32_dpp: ONE VALU instruction per step and channel (it was shuffle + compare +
+    // add: ~55 LDS operations and ~200 VALU per step of 8 channels, which -- not HBM -- bounded the kernel at 99 us).
     const int key = active ? dst : -1 - lane;
-    const int prev = __shfl_up(key, 1);
+    const int prev = __builtin_amdgcn_update_dpp(key, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     const bool head = lane == 0 || prev != key;
+    const unsigned long long hm = __ballot(head);
     bool tail = true;
-    if (__ballot(!head) != 0ull) {
-      int rs = head ? lane : 0;                      // first lane of this lane's run: running maximum of the head positions
+    if (hm != ~0ull) {
+      const int rs = 63 - __clzll(hm & (~0ull >> (63 - lane)));          // first lane of this lane's run
+      const int lo = max(rs, lane & ~15);
+      const float m1 = lane - 1 >= lo ? 1.f : 0.f, m2 = lane - 2 >= lo ? 1.f : 0.f, m4 = lane - 4 >= lo ? 1.f : 0.f, m8 = lane - 8 >= lo ? 1.f : 0.f;
+      const float mb15 = ((lane & 16) && rs < (lane & ~15)) ? 1.f : 0.f;  // rows 1 and 3: the run began in an earlier row
+      const float mb31 = (lane >= 32 && rs < 32) ? 1.f : 0.f;             // rows 2 and 3: ... before lane 32
+      // 0 x inf = NaN would leak a non-finite value into a NEIGHBOURING run: such waves take the select form
+      float chk = 0.f;
 #pragma unroll
-      for (int st = 1; st < 64; st <<= 1) {
-        const int o = __shfl_up(rs, st);
-        if (lane >= st) rs = max(rs, o);
-      }
+      for (int cc = 0; cc < CB; ++cc) chk += fabsf(g[cc]);
+      if (__ballot(!(chk < __builtin_inff())) == 0ull) {
 #pragma unroll
-      for (int cc = 0; cc < CB; ++cc) {
+        for (int cc = 0; cc < CB; ++cc)
+          asm volatile("s_nop 1\n\t"
+                       "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_dpp %0, %0, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_dpp %0, %0, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_dpp %0, %0, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_dpp %0, %0, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_dpp %0, %0, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                       "s_nop 1"
+                       : "+v"(g[cc])
+                       : "v"(m1), "v"(m2), "v"(m4), "v"(m8), "v"(mb15), "v"(mb31));
+      } else {
 #pragma unroll
-        for (int st = 1; st < 64; st <<= 1) {
-          const float o = __shfl_up(g[cc], st);
-          if (lane - st >= rs) g[cc] += o;
+        for (int cc = 0; cc < CB; ++cc) {
+#pragma unroll
+          for (int st = 1; st < 64; st <<= 1) {
+            const float o = __shfl_up(g[cc], st);
+            if (lane - st >= rs) g[cc] += o;
+          }
         }
       }
-      const int next = __shfl_down(key, 1);
-      tail = lane == 63 || next != key;
+      tail = lane == 63 || ((hm >> (lane + 1)) & 1ull);
     }
     if (active && tail) {
 #pragma unroll
@@ -465,6 +493,51 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, in
     if (cc < nc) out[((size_t)bi * c + c0 + cc) * n + pt] = sum3<CM>(w0, p0[cc], w1, p1[cc], w2, p2[cc]);
 }
 
+// Round 6: the global-gather form above is bound by its gather LATENCY (PMC r05: 1.6 TB/s, no byte wasted): a wave's 24 gathers wait on its index
+// loads, then its stores on the gathers, and 16 K such waves run in two rounds.  Here a workgroup stages IL_CB channel rows of the known
+// cloud in LDS (they are consecutive in memory: one coalesced copy), and every thread interpolates IL_PT points from LDS -- index / weight
+// loads of all its points in flight at once, LDS gathers (~50 clocks instead of an L2 round trip), coalesced stores.  Same sum3, bit-exact.
+constexpr int IL_CB = 4, IL_PT = 4;
+template <int CM>
+__global__ __launch_bounds__(256) void three_interpolate_lds_kernel(int c, int m, int n, const float* __restrict__ points,
+                                                                    const int32_t* __restrict__ idx, const float* __restrict__ weight,
+                                                                    float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float s_rows[];   // [IL_CB][m]
+  const int bi = blockIdx.z, c0 = blockIdx.y * IL_CB;
+  const int nc = min(IL_CB, c - c0);
+  const int p0 = blockIdx.x * (256 * IL_PT) + threadIdx.x;
+  int i0[IL_PT], i1[IL_PT], i2[IL_PT];
+  float w0[IL_PT], w1[IL_PT], w2[IL_PT];
+#pragma unroll
+  for (int j = 0; j < IL_PT; ++j) {                 // (issued before the staging copy: both are in flight together)
+    const int pt = min(p0 + j * 256, n - 1);
+    const int32_t* ip = idx + ((size_t)bi * n + pt) * 3;
+    const float* wp = weight + ((size_t)bi * n + pt) * 3;
+    i0[j] = ip[0]; i1[j] = ip[1]; i2[j] = ip[2];
+    w0[j] = wp[0]; w1[j] = wp[1]; w2[j] = wp[2];
+  }
+  const float* src = points + ((size_t)bi * c + c0) * m;
+  const int len = nc * m;
+  if (((uintptr_t)src & 15u) == 0 && (len & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < len; i += 1024) *reinterpret_cast<float4*>(s_rows + i) = *reinterpret_cast<const float4*>(src + i);
+  } else {
+    for (int i = threadIdx.x; i < len; i += 256) s_rows[i] = src[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < IL_PT; ++j) {
+    const int pt = p0 + j * 256;
+    if (pt < n) {
+#pragma unroll
+      for (int cc = 0; cc < IL_CB; ++cc)
+        if (cc < nc) {
+          const float* row = s_rows + cc * m;
+          out[((size_t)bi * c + c0 + cc) * n + pt] = sum3<CM>(w0[j], row[i0[j]], w1[j], row[i1[j]], w2[j], row[i2[j]]);
+        }
+    }
+  }
+}
+
 // gradient: grad_points[b][c][idx[b][i][k]] += grad_out[b][c][i] * weight[b][i][k].  Like the grouping gradient: `cb` channel rows of one
 // cloud accumulate in LDS ([cb][m] floats, LDS atomics; a point's three indices and weights are loaded once for the cb channels) and are
 // added to grad_points by coalesced read-modify-writes; the global-atomic form stays for known clouds that do not fit.
@@ -562,18 +635,19 @@ int u3d_furthest_point_sampling(int b, int n, int m, const float* points, float*
   }
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)n * 3 * sizeof(float);
-  // (clouds beyond 5461 points stage more than 64 KB: opt in to the larger dynamic LDS size, once per instantiation)
+  // (clouds beyond 5461 points stage more than 64 KB: opt in to the larger dynamic LDS size.  The attribute belongs to the (device, function)
+  // pair, so it is set on every such launch -- a host-side table lookup -- and checked: if the runtime refuses it the launch goes to
+  // fps_kernel_large when the caller brought `temp`, and fails loudly otherwise)
 #define FPS_CM(T, P, CM)                                                                                                             \
   do {                                                                                                                               \
-    if (lds > 65536) {                                                                                                               \
-      static bool big_lds = false;                                                                                                   \
-      if (!big_lds) {                                                                                                                \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<T, P, CM>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                  8192 * 3 * (int)sizeof(float));                                                                    \
-        big_lds = true;                                                                                                              \
-      }                                                                                                                              \
+    if (lds > 65536 &&                                                                                                               \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<T, P, CM>), hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                            8192 * 3 * (int)sizeof(float)) != hipSuccess) {                                                          \
+      (void)hipGetLastError();                                                                                                       \
+      big_lds_refused = true;                                                                                                        \
+    } else {                                                                                                                         \
+      hipLaunchKernelGGL((fps_kernel<T, P, CM>), dim3(b), dim3(T), lds, s, n, m, lg, points, idx);                                   \
     }                                                                                                                                \
-    hipLaunchKernelGGL((fps_kernel<T, P, CM>), dim3(b), dim3(T), lds, s, n, m, lg, points, idx);                                     \
   } while (0)
 #define FPS(T, P)                                                    \
   do {                                                               \
@@ -583,6 +657,7 @@ int u3d_furthest_point_sampling(int b, int n, int m, const float* points, float*
   } while (0)
   // small clouds: U3D_FPS_SMALL_THREADS / 64 waves keep the per-selection chain short; larger ones spread over U3D_FPS_BIG_THREADS / 64
   constexpr int ST = U3D_FPS_SMALL_THREADS, BT = U3D_FPS_BIG_THREADS;
+  bool big_lds_refused = false;
   if (n <= 256) FPS(256, 1);
   else if (n <= 512) FPS(ST, 512 / ST);
   else if (n <= 1024) FPS(ST, 1024 / ST);
@@ -595,6 +670,10 @@ int u3d_furthest_point_sampling(int b, int n, int m, const float* points, float*
   }
 #undef FPS
 #undef FPS_CM
+  if (big_lds_refused) {
+    if (!temp) return 3;
+    U3D_PO_LAUNCH_CM(fps_kernel_large, dim3(b), dim3(1024), 0, s, n, m, lg, points, temp, idx);
+  }
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -671,8 +750,13 @@ int u3d_three_interpolate(int b, int c, int m, int n, const float* points, const
   if (b == 0 || c == 0 || n == 0) return 0;
   if (b > 65535 || (c + IC_CH - 1) / IC_CH > 65535) return 1;
   if (!points || !idx || !weight || !out) return 1;
-  U3D_PO_LAUNCH_CM(three_interpolate_kernel, dim3((n + 255) / 256, (c + IC_CH - 1) / IC_CH, b), dim3(256), 0, (hipStream_t)stream, c, m, n, points,
-                   idx, weight, out);
+  if (m > 0 && (size_t)m * IL_CB * sizeof(float) <= 32768 && (c + IL_CB - 1) / IL_CB <= 65535 && g_interp_lds) {
+    U3D_PO_LAUNCH_CM(three_interpolate_lds_kernel, dim3((n + 256 * IL_PT - 1) / (256 * IL_PT), (c + IL_CB - 1) / IL_CB, b), dim3(256),
+                     sizeof(float) * (size_t)m * IL_CB, (hipStream_t)stream, c, m, n, points, idx, weight, out);
+  } else {
+    U3D_PO_LAUNCH_CM(three_interpolate_kernel, dim3((n + 255) / 256, (c + IC_CH - 1) / IC_CH, b), dim3(256), 0, (hipStream_t)stream, c, m, n, points,
+                     idx, weight, out);
+  }
   return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -17,6 +17,12 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_STOP = 0.0001f;
+#ifndef U3D_FWD_HOIST
+#define U3D_FWD_HOIST 1      // forward: one wave-uniform saturation test per entry instead of four per-pixel mask chains (round 6)
+#endif
+#ifndef U3D_BWD_LIMFREE
+#define U3D_BWD_LIMFREE 1    // backward: entries in front of the tile's earliest saturation position skip the per-pixel limit test (round 6)
+#endif
 
 __device__ __forceinline__ bool rect_hits(const uint2 r, int tx, int ty) {
   const int x0 = r.x & 0xffffu, y0 = r.x >> 16, x1 = r.y & 0xffffu, y1 = r.y >> 16;
@@ -154,8 +160,13 @@ struct TileGeom {
 //     centre is finite; NaN alphas still fail the alpha >= 1/255 test);
 //   * a' >= -2.5 (conic xx <= 3.47: every covariance that went through the +0.3 low-pass has xx <= 3.34), which bounds how fast the
 //     exponent can fall along a lane's 4-pixel run -- what alpha_run needs.
-// Any entry outside these bounds (opacity above 0.98, a nearly singular or non-finite conic) sends the whole batch through the
-// loops that carry both tests, so results are identical either way.
+// Any entry outside these bounds (opacity above 0.98, a nearly singular or non-finite conic) sends the whole TILE through the loops that
+// carry both tests.  Since round 5 the two variants are NOT bit-identical: the PLAIN loops take alpha from the alpha_run recurrence (2 exp2 +
+// multiplies), the general ones from exp2(pw) per pixel, which agree to ~1e-6 relative.  The invariant that matters is that FORWARD AND
+// BACKWARD OF A TILE RUN THE SAME VARIANT (a 1/255 threshold decided one way by the forward and the other way by the backward would
+// desynchronise stop_pos from the recomputed alphas): the single-pass kernel holds it by construction, the two-pass kernels through
+// U3D_TILE_PLAIN_BIT in tile_last.  `U3D_FORCE_GENERAL` (experiment / test builds) sends every tile through the general variant, which
+// tests/test_gpu_more_parity.py compares against the product build.
 template <bool DEPTH>
 __device__ __forceinline__ lanemask_t tile_stage(const TileLds& L, const TileGeom& G, int lane, int b, uint32_t limit, bool& plain) {
   const uint32_t s = (uint32_t)b * U3D_WAVE + (uint32_t)lane;
@@ -176,6 +187,9 @@ __device__ __forceinline__ lanemask_t tile_stage(const TileLds& L, const TileGeo
     L.S[o * L.sstride] = __builtin_amdgcn_exp2f(a1 + a1);
     ok = a1 <= 0.f && a1 >= -2.5f && c1 <= 0.f && b1 * b1 <= (4.f * (1.f - 1e-5f)) * (a1 * c1) && co.w <= 0.98f && fabsf(m.x) < 1e30f && fabsf(m.y) < 1e30f;
   }
+#ifdef U3D_FORCE_GENERAL
+  ok = false;
+#endif
   plain = __ballot(!ok) == 0ull;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -241,9 +255,58 @@ __device__ __forceinline__ bool tile_forward(const TileLds& L, const TileGeom& G
       const float invd = DEPTH ? L.D[j] : 0.f;
       const float dy = A.y - pyf;
       const float bdy = A.w * dy, cdy2 = (Q.x * dy) * dy;
-      lanemask_t contrib = 0ull, stopped = 0ull, m_stop[4];
+      lanemask_t contrib = 0ull, m_stop[4];
+      [[maybe_unused]] lanemask_t stopped = 0ull;
       float ar[4];
       if (PLAIN) alpha_run(A.x, A.z, bdy, cdy2, Q.y, L.S[j * L.sstride], pxf[0], ar);
+#if U3D_FWD_HOIST
+      // Round 6: the saturation test leaves the per-pixel chains.  A pixel saturates once, and with the reference's large splats the pixels
+      // of a tile do so within its last few entries; everywhere else `T (1 - alpha) < 1e-4` is false for all 256 pixels.  So each pixel
+      // takes  we = ok ? alpha T : 0,  Tn = T - we  (one compare, one select, no scalar mask algebra), ONE test of the smallest Tn over
+      // the lane's pixels decides wave-uniformly whether any pixel stops here, and only then the masks of the general form are built.
+      // `Tn < 1e-4` is exactly `ok & (T (1 - alpha) < 1e-4)`: a pixel that skips the entry keeps its T, which is never below 1e-4
+      // (live: it has not stopped; finished: the stopping entry was not blended).  Same values, bit for bit.
+      float wv[4], tn[4];
+      lanemask_t m_okv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float pw = 0.f;
+        if (!PLAIN) {
+          const float dx = A.x - pxf[k];
+          pw = fmaf(fmaf(A.z, dx, bdy), dx, cdy2);
+          ar[k] = Q.y * __builtin_amdgcn_exp2f(pw);
+        }
+        const float alpha = PLAIN ? ar[k] : min_099(ar[k]);
+        m_okv[k] = PLAIN ? __builtin_amdgcn_fcmpf(alpha, amin[k], U3D_FCMP_OGE)
+                         : __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE) & __builtin_amdgcn_fcmpf(alpha, amin[k], U3D_FCMP_OGE);
+        wv[k] = mask_sel0(m_okv[k], alpha * F.Tr[k]);
+        tn[k] = F.Tr[k] - wv[k];
+      }
+      float tmin;
+      asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmin) : "v"(tn[0]), "v"(tn[1]), "v"(tn[2]));
+      asm("v_min_f32_e32 %0, %1, %2" : "=v"(tmin) : "v"(tmin), "v"(tn[3]));
+      const bool some_stop = __builtin_amdgcn_fcmpf(tmin, T_STOP, U3D_FCMP_OLT) != 0ull;   // wave-uniform
+      contrib = (m_okv[0] | m_okv[1]) | (m_okv[2] | m_okv[3]);
+      if (some_stop) {   // the pixels that saturate here do not blend the entry: their weight goes back to 0, their T stays
+        contrib = 0ull;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          m_stop[k] = __builtin_amdgcn_fcmpf(tn[k], T_STOP, U3D_FCMP_OLT);
+          contrib |= m_okv[k] & ~m_stop[k];
+          stopped |= m_stop[k];
+          wv[k] = mask_sel(m_stop[k], 0.f, wv[k]);
+          tn[k] = F.Tr[k] - wv[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        F.C0[k] = fmaf(Q.z, wv[k], F.C0[k]);
+        F.C1[k] = fmaf(Q.w, wv[k], F.C1[k]);
+        F.C2[k] = fmaf(R.x, wv[k], F.C2[k]);
+        if (DEPTH) F.Dv[k] = fmaf(invd, wv[k], F.Dv[k]);
+        F.Tr[k] = tn[k];
+      }
+#else
 #pragma unroll
       for (int k = 0; k < 4; ++k) {   // one basic block: the four pixels' dependency chains interleave
         float pw = 0.f;
@@ -268,8 +331,13 @@ __device__ __forceinline__ bool tile_forward(const TileLds& L, const TileGeom& G
         F.Tr[k] -= we;
         stopped |= m_stop[k];
       }
+#endif
       if (contrib != 0ull) { jlast = j; blast = b; }
+#if U3D_FWD_HOIST
+      if (some_stop) {         // wave-uniform: pixels saturating at this Gaussian (the last few entries of a tile's walk)
+#else
       if (stopped != 0ull) {   // rare, wave-uniform: pixels saturating at this Gaussian
+#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           amin[k] = mask_sel(m_stop[k], 2.f, amin[k]);
@@ -324,6 +392,12 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
   typedef __attribute__((address_space(3))) float lds_float;
   const uint32_t acc_lane = (uint32_t)(uintptr_t)(lds_float*)&L.acc[0][0] + 4u * (uint32_t)bank;
   const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
+#if U3D_BWD_LIMFREE
+  // Round 6: the earliest position limit of the tile's 256 pixels (wave-uniform).  An entry in front of it is seen by EVERY pixel, so its
+  // per-pixel `pos < lim` compares and their mask algebra are skipped -- with the reference's splats the pixels of a tile saturate
+  // within its last few entries, i.e. this is the common case of the walk.  (A pixel outside the image has lim = 0: such tiles keep the test.)
+  const uint32_t lmin = u3d_wave_min_u32(min(min(lim[0], lim[1]), min(lim[2], lim[3])));
+#endif
   for (int b = nb - 1; b >= 0; --b) {
     lanemask_t bal = staged_bal;
     if (b != staged) { bool plain; bal = tile_stage<HAS_INVD>(L, G, lane, b, wmax, plain); staged = b; staged_bal = bal; }
@@ -341,6 +415,7 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
       float dx[4], ae[4], ar[4];
       lanemask_t any = 0ull;
       if (PLAIN) alpha_run(A.x, A.z, bdy, cdy2, Q.y, L.S[j * L.sstride], pxf[0], ar);   // the forward's own values, bit for bit
+      lanemask_t m_e[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         dx[k] = A.x - pxf[k];
@@ -349,10 +424,19 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
           pw = fmaf(fmaf(A.z, dx[k], bdy), dx[k], cdy2);
           ar[k] = Q.y * __builtin_amdgcn_exp2f(pw);
         }
-        const float araw = ar[k];   // opacity * G (alpha before the 0.99 clamp)
-        const lanemask_t m_a = (PLAIN ? ~0ull : __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE)) & __builtin_amdgcn_fcmpf(araw, ALPHA_MIN, U3D_FCMP_OGE);
-        ae[k] = mask_combine_sel0<false>(m_a, __builtin_amdgcn_uicmp(pos, lim[k], U3D_ICMP_ULT), any, araw);
+        // opacity * G (alpha before the 0.99 clamp) against the 1/255 skip
+        m_e[k] = (PLAIN ? ~0ull : __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE)) & __builtin_amdgcn_fcmpf(ar[k], ALPHA_MIN, U3D_FCMP_OGE);
       }
+#if U3D_BWD_LIMFREE
+      if (__builtin_amdgcn_readfirstlane(pos) >= lmin)    // wave-uniform: only entries at or behind the tile's earliest limit need the per-pixel test
+#endif
+      {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m_e[k] &= __builtin_amdgcn_uicmp(pos, lim[k], U3D_ICMP_ULT);
+      }
+      any = (m_e[0] | m_e[1]) | (m_e[2] | m_e[3]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ae[k] = mask_sel0(m_e[k], ar[k]);
       if (any == 0ull) continue;
       float m0, mx, mxx, g_r, g_g, g_b, g_d = 0.f;
 #pragma unroll

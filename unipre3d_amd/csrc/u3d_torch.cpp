@@ -22,7 +22,7 @@
 #ifndef U3D_BINDING_NO_SPARSE
 #define U3D_BINDING_NO_SPARSE 0   /* experiments: 1 = never ask for U3D_FLAG_SPARSE_BWD */
 #endif
-constexpr int64_t kSparseMinP = 4096;   // the library honours U3D_FLAG_SPARSE_BWD above its LDS-sort limit (U3D_LDS_SORT_MAX, u3d_common.h)
+constexpr int64_t kSparseMinP = U3D_SPARSE_BWD_MIN_P;   // the library honours U3D_FLAG_SPARSE_BWD above its LDS-sort limit (static_assert in u3d_common.h)
 
 namespace {
 

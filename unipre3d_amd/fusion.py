@@ -12,7 +12,8 @@ import torch.nn as nn
 from . import _lib
 
 LIB_PATH = os.path.join(_lib.LIB_DIR, "libunipre3d_fusion.so")   # (U3D_LIB_DIRNAME: experiment builds, see _lib.py)
-EXPORTS = ("u3d_zbuffer_fusion_forward", "u3d_zbuffer_fusion_backward")
+EXPORTS = ("u3d_zbuffer_fusion_forward", "u3d_zbuffer_fusion_backward", "u3d_fusion_abi_version")
+ABI_VERSION = 2
 _fu = None
 
 
@@ -24,9 +25,12 @@ def load() -> ctypes.CDLL:
         lib = ctypes.CDLL(LIB_PATH)
         vp, i, f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
         lib.u3d_zbuffer_fusion_forward.argtypes = [i, i, i, i, i, f, f, f, f, vp, vp, vp, vp, vp, vp]
-        lib.u3d_zbuffer_fusion_backward.argtypes = [i, i, i, i, i, vp, vp, vp, vp]
+        lib.u3d_zbuffer_fusion_backward.argtypes = [i, i, i, i, i, vp, vp, vp, vp, vp]
+        lib.u3d_fusion_abi_version.argtypes = []
         for n in EXPORTS:
             getattr(lib, n).restype = ctypes.c_int
+        if lib.u3d_fusion_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH}: ABI {lib.u3d_fusion_abi_version()}, this module binds ABI {ABI_VERSION}: rebuild (`make -C unipre3d_amd/csrc`)")
         _fu = lib
     return _fu
 
@@ -44,24 +48,25 @@ class _ZBufferGather(torch.autograd.Function):
         cp, feat = camera_points.contiguous().float(), image_features.contiguous().float()
         mapped = torch.empty(B, N, C, dtype=torch.float32, device=cp.device)
         sel = torch.empty(B, N, dtype=torch.int32, device=cp.device)
-        zbuf = torch.empty(B * H * W, dtype=torch.int32, device=cp.device)
+        zbuf = torch.empty(B * H * W, dtype=torch.int64, device=cp.device)     # winner table: (depth bits << 32 | first winner) per pixel
         rc = load().u3d_zbuffer_fusion_forward(B, N, C, H, W, fx, fy, cx, cy, _lib.ptr(cp), _lib.ptr(feat), _lib.ptr(mapped),
                                                _lib.ptr(sel), _lib.ptr(zbuf), _stream_ptr(cp.device))
         if rc != 0:
             raise RuntimeError(f"u3d_zbuffer_fusion_forward failed with code {rc}")
-        ctx.save_for_backward(sel)
+        ctx.save_for_backward(sel, zbuf)
         ctx.shape = (B, N, C, H, W)
         ctx.mark_non_differentiable(sel)
         return mapped, sel
 
     @staticmethod
     def backward(ctx, grad_mapped, _gs):
-        (sel,) = ctx.saved_tensors
+        sel, zbuf = ctx.saved_tensors
         B, N, C, H, W = ctx.shape
-        grad_feat = torch.zeros(B, C, H, W, dtype=torch.float32, device=sel.device)
+        # gather form: the kernel writes every element of the (B,C,H,W) gradient exactly once (no zero-fill + scatter)
+        grad_feat = torch.empty(B, C, H, W, dtype=torch.float32, device=sel.device)
         g = grad_mapped.contiguous().float()
         from .rasterizer import _stream_ptr
-        rc = load().u3d_zbuffer_fusion_backward(B, N, C, H, W, _lib.ptr(g), _lib.ptr(sel), _lib.ptr(grad_feat), _stream_ptr(sel.device))
+        rc = load().u3d_zbuffer_fusion_backward(B, N, C, H, W, _lib.ptr(g), _lib.ptr(sel), _lib.ptr(zbuf), _lib.ptr(grad_feat), _stream_ptr(sel.device))
         if rc != 0:
             raise RuntimeError(f"u3d_zbuffer_fusion_backward failed with code {rc}")
         return None, grad_feat, None, None, None, None

@@ -21,7 +21,12 @@ def focal_l2_weights(gt: torch.Tensor, bg_color, non_bg_rate: float, bg_rate: fl
     """(N,1,H,W) per-pixel weight: pixels whose 3 gt channels are all isclose(bg, atol=1e-6, rtol=1e-5)
     get 2*bg/(bg+non_bg), the rest 2*non_bg/(bg+non_bg) (utils/loss_utils.py:28-38)."""
     # 0-dim HOST tensors like the reference's `torch.tensor(bg_color[0])`: no H2D copy per call, so the loss can sit inside a HIP-graph capture
-    bg = [torch.tensor(float(c), dtype=gt.dtype) for c in bg_color]
+    # (a TENSOR background -- e.g. the batch's device-resident `bg` -- is indexed where it lives: float(c) on it would be one device->host
+    # synchronisation per channel, which is exactly what a capture cannot contain)
+    if torch.is_tensor(bg_color):
+        bg = [bg_color[i].to(gt.dtype) for i in range(3)]
+    else:
+        bg = [torch.tensor(float(c), dtype=gt.dtype) for c in bg_color]
     is_bg = torch.isclose(gt[:, 0], bg[0], atol=1e-6) & torch.isclose(gt[:, 1], bg[1], atol=1e-6) & \
         torch.isclose(gt[:, 2], bg[2], atol=1e-6)
     w_non = 2 * non_bg_rate / (bg_rate + non_bg_rate)
