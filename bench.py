@@ -495,7 +495,7 @@ def fusion_region(dev, seed=12):
     feat = torch.randn(B, C, H, W, generator=g)
     cam, fd = torch.from_numpy(cam_h).to(dev), feat.to(dev)
     mapped, sel = torch.empty(B, N, C, device=dev), torch.empty(B, N, dtype=torch.int32, device=dev)
-    zbuf = torch.empty(B * H * W, dtype=torch.int64, device=dev)
+    zbuf = torch.empty((lib.u3d_zbuffer_fusion_zbuf_bytes(B, H, W) + 7) // 8, dtype=torch.int64, device=dev)
     strm = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def fwd():
@@ -696,49 +696,68 @@ def per_view_region(batch, B, P, V, H, W, loss_kind, steps=9):
            "operator_calls_per_step": 2 * B * V, "us_per_forward_backward_pair": 1e6 * el / steps / (B * V), "final_loss": float(l),
            "what": "reference call pattern unchanged: render_predicted per object and view (renderer.render_predicted: ONE binding call per "
                    "view, u3d_render_view_forward/_backward over the C-ABI), torch.stack, torch loss, loss.backward(); every step fenced by a synchronise"}
-    # The operator's OWN share of this route, measured directly instead of as a difference of two host-bound loops:
-    # (a) GPU: HIP-event time of the operator's own kernels over whole steps of the loop above (every launch scope of the C-ABI recorded);
-    # (b) host: issue time of the 2 x B*V bare binding calls (`_C().render_view` forward + its autograd backward) on pre-sliced inputs,
-    #     with no wrapper, no slicing, no stack, no loss around them.
+    # The operator's OWN share of this route, measured directly instead of as a difference of two host-bound loops.  The
+    # probe: the 2 x B*V bare binding calls of a step -- `_C().render_view` forward for every (object, view) on pre-sliced leaves (one private
+    # leaf set per view: no gradient-accumulation kernels), then ONE autograd pass over the B*V outputs, i.e. the operator's backward nodes as
+    # the engine runs them in the real loop -- with no wrapper, slicing, stack or loss around them.
+    #   operator_host_ms: host time to ISSUE that sequence (queue empty before, no synchronisation inside);
+    #   operator_gpu_ms:  the same sequence captured in a HIP graph and replayed: the GPU time of the operator's own kernels back to back,
+    #                     free of the host gaps that dominate the eager route (HIP-event scopes around eager launches measure those gaps).
     try:
-        step_fn()
-        torch.cuda.synchronize()
-        _lib.profile_begin(16384)
-        for _ in range(3):
-            step_fn()
-        torch.cuda.synchronize()
-        pr = _lib.profile_end()
-        out["operator_gpu_ms"] = sum(ms for ms, _ in pr.values()) / 3
-        out["operator_gpu_scopes_per_step"] = sum(c for _, c in pr.values()) / 3
         from unipre3d_amd import rasterizer as _rzb
         Cb = _rzb._C()
         with torch.no_grad():
             gs0 = head.process_object_output(batch.raw, batch.center, batch.offset_scale)
         names = ("xyz", "opacity", "scaling", "rotation", "features_dc", "features_rest")
-        sl = [[gs0[k][i].contiguous().requires_grad_(True) for k in names] for i in range(B)]
+        leaves = [[[gs0[k][i].clone().requires_grad_(True) for k in names] for v in range(V)] for i in range(B)]
+        flat_leaves = [t for i in range(B) for v in range(V) for t in leaves[i][v]]
         cam = [[(batch.world_view[i, v].contiguous(), batch.full_proj[i, v].contiguous(), batch.camera_center[i, v].contiguous()) for v in range(V)]
                for i in range(B)]
-        gcol = torch.ones(3, H, W, device=batch.raw.device)
+        gcols = [torch.ones(3, H, W, device=batch.raw.device) for _ in range(B * V)]
         tanfov = math.tan(batch.fov_deg * math.pi / 360)
 
-        def bare():
+        def bare_seq():
+            cols = []
+            for i in range(B):
+                for v in range(V):
+                    x = leaves[i][v]
+                    wv, fp, cc = cam[i][v]
+                    cols.append(Cb.render_view(x[0], x[1], x[2], x[3], x[4], x[5], wv, fp, cc, batch.bg, H, W, tanfov, tanfov, 1.0, 1, renderer._FAST_FLAGS)[0])
+            return torch.autograd.grad(cols, flat_leaves, gcols)
+
+        def bare_host():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(B):
-                x = sl[i]
-                for v in range(V):
-                    wv, fp, cc = cam[i][v]
-                    color = Cb.render_view(x[0], x[1], x[2], x[3], x[4], x[5], wv, fp, cc, batch.bg, H, W, tanfov, tanfov, 1.0, 1, renderer._FAST_FLAGS)[0]
-                    torch.autograd.grad(color, x, gcol)
+            bare_seq()
             dt = time.perf_counter() - t0
             torch.cuda.synchronize()
             return dt
-        bare()
-        hs = sorted(bare() for _ in range(5))
+        bare_host()
+        hs = sorted(bare_host() for _ in range(5))
         out["operator_host_ms"] = 1e3 * hs[2]
         out["operator_host_ms_min"] = 1e3 * hs[0]
-        out["operator_what"] = ("operator_gpu_ms: sum of the HIP-event scopes of the operator's own kernels per step of the unchanged loop; operator_host_ms: "
-                                "host issue time of the 2 x B*V bare binding calls (render_view forward + autograd backward) on pre-sliced inputs (median of 5)")
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                bare_seq()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                bare_seq()
+            for _ in range(3):
+                gr.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                gr.replay()
+            torch.cuda.synchronize()
+            out["operator_gpu_ms"] = 1e3 * (time.perf_counter() - t0) / 20
+            del gr
+        out["operator_what"] = ("the 2 x B*V bare binding calls of a step (render_view forward per object and view on private leaves, then one autograd pass "
+                                "over the B*V outputs): operator_host_ms = host time to issue them (median of 5), operator_gpu_ms = the same sequence "
+                                "replayed from a HIP graph (its kernels back to back, no host gaps)")
     except Exception as e:  # noqa: BLE001
         out["operator_error"] = repr(e)[:300]
         torch.cuda.synchronize()

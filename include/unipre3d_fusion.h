@@ -14,12 +14,14 @@
  *      (B,C,H,W) gradient written exactly ONCE (no zero-fill + scatter) -- then the rows of tied points are added.
  * camera_points [B][N][4] are the points already transformed by the world-to-camera matrix (the reference's own
  * torch.matmul at :42-45 stays in PyTorch so that pixel rounding is bit-identical).
- * zbuf: B*H*W uint64, written by the forward and READ by the backward (keep it with sel); N < 2^32.
+ * zbuf: u3d_zbuffer_fusion_zbuf_bytes(B, H, W) bytes (B*H*W uint64 winner words), written by the forward and READ by the backward
+ *       (keep it with sel); N < 2^32.
  * grad_features need NOT be initialised (ABI 2; ABI 1 accumulated with float atomics into a caller-zeroed buffer).
  * Returns 0 ok, 1 invalid argument, 2 unsupported shape, 3 launch failure.
  */
 #ifndef UNIPRE3D_FUSION_H
 #define UNIPRE3D_FUSION_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -29,6 +31,7 @@ int u3d_zbuffer_fusion_forward(int B, int N, int C, int H, int W, float fx, floa
                                uint64_t* zbuf, void* stream);
 int u3d_zbuffer_fusion_backward(int B, int N, int C, int H, int W, const float* grad_mapped, const int32_t* sel,
                                 const uint64_t* zbuf, float* grad_features, void* stream);
+size_t u3d_zbuffer_fusion_zbuf_bytes(int B, int H, int W);
 #define U3D_FUSION_ABI_VERSION 2
 int u3d_fusion_abi_version(void);
 #ifdef __cplusplus

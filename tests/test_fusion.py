@@ -114,6 +114,7 @@ def test_gather_form_backward_writes_every_element_once_and_adds_tied_points(H, 
     gen = torch.Generator().manual_seed(H * 131 + W)
     B, N = 3, 60
     cp = torch.cat([torch.randn(B, N, 2, generator=gen) * 0.4, 1.0 + torch.rand(B, N, 1, generator=gen), torch.ones(B, N, 1)], dim=-1)
+    cp[:, 3] = torch.tensor([0.01, -0.02, 0.9, 1.0])      # image centre, nearer than every random point (z in [1, 2]): a certain winner
     cp[:, 10] = cp[:, 3]; cp[:, 40] = cp[:, 3]            # three points on one pixel at the SAME depth: all three are winners
     cp[:, 20, :2] = cp[:, 5, :2] * (cp[:, 20, 2:3] / cp[:, 5, 2:3])   # same pixel, farther: occluded
     f = float(min(H, W))

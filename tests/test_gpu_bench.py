@@ -150,8 +150,7 @@ def test_default_line_carries_the_other_configs_and_the_noop_control():
     assert pv["noop_operator_ms"] > 0 and abs(pv["operator_share_ms"] - (pv["ms_per_step"] - pv["noop_operator_ms"])) < 1e-9
     # the operator's own share, measured directly: its kernels' HIP-event time per step and the host time of its 2 x B*V bare binding calls
     assert "operator_error" not in pv, pv.get("operator_error")
-    assert 0 < pv["operator_gpu_ms"] < pv["ms_per_step"] and 0 < pv["operator_host_ms"] < pv["ms_per_step"]
-    assert pv["operator_gpu_scopes_per_step"] >= 4 * 128                               # 2 scopes forward + 2 backward per view
+    assert 0 < pv["operator_gpu_ms"] < pv["ms_per_step"] and pv["operator_host_ms"] > 0 and pv["operator_gpu_ms"] < pv["graph_replay_ms"]
     fr = out["forward_rasterizer"]
     assert 0 < fr["frac_pmc_bytes"] <= fr["frac_of_8TBs"]
     # rows N1 / N4a in the driver's own line: per operator microseconds, roofline, CPU-oracle baseline, equality with the oracle

@@ -311,13 +311,20 @@ __global__ __launch_bounds__(256) void group_points_grad_lds_kernel(int c, int n
   const int32_t* ip = idx + (size_t)bi * total;
   const float* go = grad_out + ((size_t)bi * c + c0) * total;
   const int lane = threadIdx.x & 63;
-  for (int e0 = 0; e0 < total; e0 += 256) {         // (wave-uniform trip count: the run merge below shuffles across the wave)
-    const int e = e0 + threadIdx.x;
-    const bool active = e < total;
-    const int dst = active ? ip[e] : 0;
-    float g[CB];                                    // all loads of the step in flight before the first LDS atomic
+  // (software pipeline: the loads of step s + 1 are issued before step s is processed, so a wave's own HBM latency overlaps its scan and its
+  //  LDS updates instead of waiting for another wave to fill the gap)
+  bool active = (int)threadIdx.x < total;
+  int dst = active ? ip[threadIdx.x] : 0;
+  float g[CB];
 #pragma unroll
-    for (int cc = 0; cc < CB; ++cc) g[cc] = (active && cc < nc) ? go[(size_t)cc * total + e] : 0.f;
+  for (int cc = 0; cc < CB; ++cc) g[cc] = (active && cc < nc) ? go[(size_t)cc * total + threadIdx.x] : 0.f;
+  for (int e0 = 0; e0 < total; e0 += 256) {         // (wave-uniform trip count: the run merge below works across the wave)
+    const int en = e0 + 256 + threadIdx.x;
+    const bool an = en < total;
+    const int dstn = an ? ip[en] : 0;
+    float gn[CB];
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) gn[cc] = (an && cc < nc) ? go[(size_t)cc * total + en] : 0.f;
     // Ball-query index sets pad every group with copies of its first hit: runs of EQUAL CONSECUTIVE destinations, which would meet in one LDS
     // word (the compare-and-swap collapses there).  A wave that holds such a run sums it first -- segmented inclusive scan over the run, the
     // run's last lane keeps the total -- and only the tails update LDS.  Waves without adjacent duplicates (gather, three_nn-style indices)
@@ -375,6 +382,9 @@ __global__ __launch_bounds__(256) void group_points_grad_lds_kernel(int c, int n
       for (int cc = 0; cc < CB; ++cc)
         if (cc < nc) lds_add_f32(&s_acc[cc * n + dst], g[cc]);
     }
+    active = an; dst = dstn;
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) g[cc] = gn[cc];
   }
   __syncthreads();
   float* gp = grad_points + ((size_t)bi * c + c0) * n;
@@ -497,7 +507,13 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, in
 // loads, then its stores on the gathers, and 16 K such waves run in two rounds.  Here a workgroup stages IL_CB channel rows of the known
 // cloud in LDS (they are consecutive in memory: one coalesced copy), and every thread interpolates IL_PT points from LDS -- index / weight
 // loads of all its points in flight at once, LDS gathers (~50 clocks instead of an L2 round trip), coalesced stores.  Same sum3, bit-exact.
-constexpr int IL_CB = 4, IL_PT = 4;
+#ifndef U3D_IL_CB
+#define U3D_IL_CB 4
+#endif
+#ifndef U3D_IL_PT
+#define U3D_IL_PT 4
+#endif
+constexpr int IL_CB = U3D_IL_CB, IL_PT = U3D_IL_PT;
 template <int CM>
 __global__ __launch_bounds__(256) void three_interpolate_lds_kernel(int c, int m, int n, const float* __restrict__ points,
                                                                     const int32_t* __restrict__ idx, const float* __restrict__ weight,
@@ -601,11 +617,15 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(int c, int 
 }
 
 // channel rows per workgroup of the LDS-accumulating gradient kernels: a power of two <= 16 such that the rows of `len` floats fit
-// 64 KB of LDS and the launch has on the order of a thousand workgroups (b * c rows in all); 0: one row does not fit -> global atomics
+// 64 KB of LDS and the launch has on the order of three thousand workgroups (b * c rows in all); 0: one row does not fit -> global atomics.
+// (Round 6 sweep at the reference's shapes: grouping gradient 32 x 384 rows of 1024: 1 / 2 / 4 / 8 / 16 rows -> 87 / 72 / 70 / 85 / 129 us;
+//  three_interpolate gradient 16 x 256 rows of 512: 48 / 44 / 49 / 50 / 72 us.  Fewer rows = more, smaller workgroups per CU (LDS-limited
+//  residency: 8 rows of 1024 floats allow 5 workgroups per CU = 1280 slots for 1536 workgroups, i.e. a second round one fifth full),
+//  more rows = fewer re-reads of the index array; rounds 1-5 aimed at a thousand workgroups.)
 inline int lds_rows(int len, int b, int c) {
   const int fit = 16384 / (len > 0 ? len : 1);
   if (fit < 1) return 0;
-  const long long want = ((long long)b * c + 1023) / 1024;
+  const long long want = ((long long)b * c + 3071) / 3072;
   int cb = 1;
   while (cb * 2 <= 16 && cb * 2 <= fit && cb * 2 <= want) cb *= 2;
   return cb;
@@ -710,7 +730,9 @@ int u3d_group_points_grad(int b, int c, int n, int npoints, int nsample, const f
   if (b > 65535 || c > 65535) return 1;
   if (!grad_out || !idx || !grad_points) return 1;
   const int total = npoints * nsample;
-  const int cb = lds_rows(n, b, c);
+  int cb = lds_rows(n, b, c);
+  static const int cb_env = getenv("U3D_GG_CB") ? atoi(getenv("U3D_GG_CB")) : 0;   // (experiment switch)
+  if (cb_env > 0 && cb > 0 && (size_t)cb_env * n * sizeof(float) <= 65536) cb = cb_env;
 #define GG(CB) hipLaunchKernelGGL((group_points_grad_lds_kernel<CB>), dim3((c + CB - 1) / CB, b), dim3(256), sizeof(float) * (size_t)CB * n, \
                                   (hipStream_t)stream, c, n, total, grad_out, idx, grad_points)
   if (cb == 16) GG(16);
@@ -766,7 +788,9 @@ int u3d_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out
   if (b == 0 || c == 0 || n == 0) return 0;
   if (b > 65535 || (c + IC_CH - 1) / IC_CH > 65535) return 1;
   if (!grad_out || !idx || !weight || !grad_points) return 1;
-  const int cb = m > 0 ? lds_rows(m, b, c) : 0;
+  int cb = m > 0 ? lds_rows(m, b, c) : 0;
+  static const int ig_env = getenv("U3D_IG_CB") ? atoi(getenv("U3D_IG_CB")) : 0;   // (experiment switch)
+  if (ig_env > 0 && cb > 0 && (size_t)ig_env * m * sizeof(float) <= 65536) cb = ig_env;
 #define IG(CB) hipLaunchKernelGGL((three_interpolate_grad_lds_kernel<CB>), dim3((c + CB - 1) / CB, b), dim3(256), sizeof(float) * (size_t)CB * m, \
                                   (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points)
   if (cb == 16) IG(16);

@@ -20,9 +20,6 @@ constexpr float T_STOP = 0.0001f;
 #ifndef U3D_FWD_HOIST
 #define U3D_FWD_HOIST 1      // forward: one wave-uniform saturation test per entry instead of four per-pixel mask chains (round 6)
 #endif
-#ifndef U3D_BWD_LIMFREE
-#define U3D_BWD_LIMFREE 1    // backward: entries in front of the tile's earliest saturation position skip the per-pixel limit test (round 6)
-#endif
 
 __device__ __forceinline__ bool rect_hits(const uint2 r, int tx, int ty) {
   const int x0 = r.x & 0xffffu, y0 = r.x >> 16, x1 = r.y & 0xffffu, y1 = r.y >> 16;
@@ -392,12 +389,6 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
   typedef __attribute__((address_space(3))) float lds_float;
   const uint32_t acc_lane = (uint32_t)(uintptr_t)(lds_float*)&L.acc[0][0] + 4u * (uint32_t)bank;
   const int nb = (int)((wmax + U3D_WAVE - 1) / U3D_WAVE);
-#if U3D_BWD_LIMFREE
-  // Round 6: the earliest position limit of the tile's 256 pixels (wave-uniform).  An entry in front of it is seen by EVERY pixel, so its
-  // per-pixel `pos < lim` compares and their mask algebra are skipped -- with the reference's splats the pixels of a tile saturate
-  // within its last few entries, i.e. this is the common case of the walk.  (A pixel outside the image has lim = 0: such tiles keep the test.)
-  const uint32_t lmin = u3d_wave_min_u32(min(min(lim[0], lim[1]), min(lim[2], lim[3])));
-#endif
   for (int b = nb - 1; b >= 0; --b) {
     lanemask_t bal = staged_bal;
     if (b != staged) { bool plain; bal = tile_stage<HAS_INVD>(L, G, lane, b, wmax, plain); staged = b; staged_bal = bal; }
@@ -415,7 +406,6 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
       float dx[4], ae[4], ar[4];
       lanemask_t any = 0ull;
       if (PLAIN) alpha_run(A.x, A.z, bdy, cdy2, Q.y, L.S[j * L.sstride], pxf[0], ar);   // the forward's own values, bit for bit
-      lanemask_t m_e[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         dx[k] = A.x - pxf[k];
@@ -424,19 +414,12 @@ __device__ __forceinline__ void tile_backward(const TileLds& L, const TileGeom& 
           pw = fmaf(fmaf(A.z, dx[k], bdy), dx[k], cdy2);
           ar[k] = Q.y * __builtin_amdgcn_exp2f(pw);
         }
-        // opacity * G (alpha before the 0.99 clamp) against the 1/255 skip
-        m_e[k] = (PLAIN ? ~0ull : __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE)) & __builtin_amdgcn_fcmpf(ar[k], ALPHA_MIN, U3D_FCMP_OGE);
+        const float araw = ar[k];   // opacity * G (alpha before the 0.99 clamp)
+        const lanemask_t m_a = (PLAIN ? ~0ull : __builtin_amdgcn_fcmpf(pw, 0.f, U3D_FCMP_OLE)) & __builtin_amdgcn_fcmpf(araw, ALPHA_MIN, U3D_FCMP_OGE);
+        // (Round 6 tried skipping the `pos < lim` compares for entries in front of the tile's EARLIEST limit -- a wave-uniform test per entry,
+        //  true for most of the walk: +3 % at C2 / C3, +1.7 % at C5.  The scalar branch costs more than the four compares and s_and it saves.)
+        ae[k] = mask_combine_sel0<false>(m_a, __builtin_amdgcn_uicmp(pos, lim[k], U3D_ICMP_ULT), any, araw);
       }
-#if U3D_BWD_LIMFREE
-      if (__builtin_amdgcn_readfirstlane(pos) >= lmin)    // wave-uniform: only entries at or behind the tile's earliest limit need the per-pixel test
-#endif
-      {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) m_e[k] &= __builtin_amdgcn_uicmp(pos, lim[k], U3D_ICMP_ULT);
-      }
-      any = (m_e[0] | m_e[1]) | (m_e[2] | m_e[3]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) ae[k] = mask_sel0(m_e[k], ar[k]);
       if (any == 0ull) continue;
       float m0, mx, mxx, g_r, g_g, g_b, g_d = 0.f;
 #pragma unroll

@@ -12,7 +12,7 @@ import torch.nn as nn
 from . import _lib
 
 LIB_PATH = os.path.join(_lib.LIB_DIR, "libunipre3d_fusion.so")   # (U3D_LIB_DIRNAME: experiment builds, see _lib.py)
-EXPORTS = ("u3d_zbuffer_fusion_forward", "u3d_zbuffer_fusion_backward", "u3d_fusion_abi_version")
+EXPORTS = ("u3d_zbuffer_fusion_forward", "u3d_zbuffer_fusion_backward", "u3d_fusion_abi_version", "u3d_zbuffer_fusion_zbuf_bytes")
 ABI_VERSION = 2
 _fu = None
 
@@ -27,8 +27,10 @@ def load() -> ctypes.CDLL:
         lib.u3d_zbuffer_fusion_forward.argtypes = [i, i, i, i, i, f, f, f, f, vp, vp, vp, vp, vp, vp]
         lib.u3d_zbuffer_fusion_backward.argtypes = [i, i, i, i, i, vp, vp, vp, vp, vp]
         lib.u3d_fusion_abi_version.argtypes = []
+        lib.u3d_zbuffer_fusion_zbuf_bytes.argtypes = [i, i, i]
         for n in EXPORTS:
             getattr(lib, n).restype = ctypes.c_int
+        lib.u3d_zbuffer_fusion_zbuf_bytes.restype = ctypes.c_size_t
         if lib.u3d_fusion_abi_version() != ABI_VERSION:
             raise RuntimeError(f"{LIB_PATH}: ABI {lib.u3d_fusion_abi_version()}, this module binds ABI {ABI_VERSION}: rebuild (`make -C unipre3d_amd/csrc`)")
         _fu = lib
@@ -48,7 +50,8 @@ class _ZBufferGather(torch.autograd.Function):
         cp, feat = camera_points.contiguous().float(), image_features.contiguous().float()
         mapped = torch.empty(B, N, C, dtype=torch.float32, device=cp.device)
         sel = torch.empty(B, N, dtype=torch.int32, device=cp.device)
-        zbuf = torch.empty(B * H * W, dtype=torch.int64, device=cp.device)     # winner table: (depth bits << 32 | first winner) per pixel
+        # winner table: (depth bits << 32 | first winner) per pixel + the "empty pixel" bitmap behind it
+        zbuf = torch.empty((load().u3d_zbuffer_fusion_zbuf_bytes(B, H, W) + 7) // 8, dtype=torch.int64, device=cp.device)
         rc = load().u3d_zbuffer_fusion_forward(B, N, C, H, W, fx, fy, cx, cy, _lib.ptr(cp), _lib.ptr(feat), _lib.ptr(mapped),
                                                _lib.ptr(sel), _lib.ptr(zbuf), _stream_ptr(cp.device))
         if rc != 0:
