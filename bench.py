@@ -54,8 +54,8 @@ def algorithmic_bytes(kind: str, P: int, R: float, T: int, HW: int) -> float:
     }[kind]
 
 
-PROFILE_ROUND = "r05"
-PROFILE_FALLBACK_ROUND = "r04"
+PROFILE_ROUND = "r06"
+PROFILE_FALLBACK_ROUND = "r05"
 # measured instruction-class issue costs on gfx950, cycles per wave64 instruction per SIMD (profiles/r01/valu_instruction_classes.txt,
 # tools/ub/ops.hip under rocprofv3 --pmc): FMA / MUL / ADD / MOV 2.13, compare / min / select / DPP 4.08, exp / rcp 8.1; a scalar
 # instruction costs the SIMD's issue port about 1.7 (profiles/r01/ub_mixed_streams.txt: fma + s_and = 1.8 x an fma alone)
@@ -116,15 +116,28 @@ def issue_roofline(config: str, default_path: bool, measured_ms: float):
     # builder-calibrated class costs.  In the launch's own measured shader cycles.
     valu_2cyc = valu * 2.0 / N_SIMD / cycles
     valu_tq = ((valu - trans) * 2.0 + trans * 8.0) / N_SIMD / cycles
-    return {"frac_valu_2cyc": valu_2cyc, "frac_valu_trans_quarter": valu_tq,
+    # the floor the MEASURED per-opcode issue costs give (tools/ub/opcost.hip -> tools/isa_reconcile.py; C2 only) and the wave-slot occupancy
+    # of the launch (profiles/<round>/sq_wait_<config>.json): what separates the kernel from that floor is vacancy, not instruction cost
+    extra = {}
+    ih = _profile_json("isa_histogram_render_fb.json") if config == "C2" else None
+    if ih:
+        fl = ih["issue_floor"]["measured_opcode_costs_whole_kernel"]
+        extra.update({"frac_opcode_costs": fl["frac"], "floor_us_opcode_costs": fl["frac"] * 1e3 * kernel_ms,
+                      "opcode_costs_source": f"profiles/{ih['_round']}/isa_histogram_render_fb.json (static ISA x measured trip counts x tools/ub/opcost.hip costs)"})
+    sw = _profile_json(f"sq_wait_{config}.json")
+    if sw and sw.get("derived"):
+        extra.update({"wave_slot_occupancy": sw["derived"]["wave_slot_occupancy"], "share_of_wave_time_in_s_waitcnt": sw["derived"]["share_of_wave_time_in_s_waitcnt"],
+                      "share_of_wave_time_waiting_for_issue": sw["derived"]["share_of_wave_time_waiting_for_issue"]})
+    return {**extra, "frac_valu_2cyc": valu_2cyc, "frac_valu_trans_quarter": valu_tq,
             "floor_us_valu_2cyc": 1e3 * valu_2cyc * kernel_ms, "floor_us_valu_trans_quarter": 1e3 * valu_tq * kernel_ms,
             "bound": "valu_issue", "kernel": "render_fb_wave_kernel", "valu_instructions_per_launch": valu, "salu_instructions_per_launch": salu,
             "transcendental_per_launch": trans, "fma_mul_add_per_launch": fma, "floor_ms_lower": 1e3 * lower, "floor_ms_by_class": 1e3 * by_class,
             "kernel_ms_rocprof": kernel_ms, "frac_lower": 1e3 * lower / kernel_ms, "frac_by_class": 1e3 * by_class / kernel_ms,
             "cycles_per_valu_instruction_per_simd": cycles * N_SIMD / valu, "shader_cycles_per_launch": cycles, "class_cycles": ISSUE_CYCLES,
-            "reading": ("frac_by_class above 1 means the kernel issues its mix faster than the calibration predicts (the class costs were measured on dependent "
-                        "chains; round 5's exponent run is mostly independent multiplies): read it as 'at the issue floor', not as an error") if 1e3 * by_class / kernel_ms > 1.0
-                       else "floor / measured duration of the tile kernel alone",
+            "reading": ("three floors, none fitted to this kernel: frac_valu_2cyc prices EVERY VALU instruction at the guide's v_fma_f32 rate (2 cycles per wave64 "
+                        "instruction and SIMD), frac_valu_trans_quarter prices the transcendentals at a quarter of that rate, frac_opcode_costs uses the per-opcode "
+                        "costs measured by tools/ub/opcost.hip (compares / selects / DPP adds ~2.8 cycles, exp2 / rcp ~5.5, a scalar instruction ~1.2 of SIMD time); "
+                        "frac_lower / frac_by_class are rounds 2-5's builder-calibrated class costs, kept for continuity"),
             "source": f"profiles/{prof['_round']}/sq_issue_{config}.json (committed rocprofv3 --pmc passes of this command; NOT measured in this "
                       f"run; class costs: builder-calibrated micro-benchmarks, profiles/r01/valu_instruction_classes.txt)"}
 
@@ -939,8 +952,8 @@ def compact_line(out, full_path=None):
         if "roofline_hbm_actual" in out:
             ex["hbm_actual_frac"] = _r(out["roofline_hbm_actual"].get("frac"))
         if ri:
-            ex["issue"] = {k: _r(ri.get(k)) for k in ("frac_valu_2cyc", "frac_valu_trans_quarter", "valu_instructions_per_launch",
-                                                       "salu_instructions_per_launch", "transcendental_per_launch") if k in ri}
+            ex["issue"] = {k: _r(ri.get(k)) for k in ("frac_valu_2cyc", "frac_valu_trans_quarter", "frac_opcode_costs", "wave_slot_occupancy",
+                                                       "valu_instructions_per_launch", "salu_instructions_per_launch", "transcendental_per_launch") if k in ri}
         if fr and "error" not in fr:
             ex["forward_rasterizer"] = {"us": _r(1e3 * fr.get("avg_ms", float("nan"))), "frac": _r(fr.get("frac_of_8TBs")), "frac_pmc": _r(fr.get("frac_pmc_bytes")),
                                         "no_invdepth_us": _r(1e3 * (fr.get("without_inverse_depth") or {}).get("avg_ms", float("nan")))}
