@@ -129,9 +129,12 @@ def test_gradient_kernels_beyond_the_lds_rows():
         out.backward(torch.from_numpy(go).cuda())
         gref = po.group_points_grad(go, idx, N)
         assert np.abs(f.grad.cpu().numpy() - gref).max() <= 1e-5 * max(np.abs(gref).max(), 1.0)
-    for (C, n, m) in ((5, 300, 17000), (19, 1000, 50)):
+    # ((40, 2048, 512): most entries on ONE destination -- the compare-and-swap accumulate's worst case; (3, 2600, 9): a tiny known cloud)
+    for (C, n, m) in ((5, 300, 17000), (19, 1000, 50), (40, 2048, 512), (3, 2600, 9)):
         feats = rng.randn(2, C, m).astype(np.float32)
         idx = rng.randint(0, m, (2, n, 3)).astype(np.int32)
+        if m == 512:
+            idx[:, ::2, 0] = 7; idx[:, 1::3, 2] = 7
         w = rng.rand(2, n, 3).astype(np.float32)
         f = torch.from_numpy(feats).cuda().requires_grad_(True)
         out = pointops.three_interpolate(f, torch.from_numpy(idx).cuda(), torch.from_numpy(w).cuda())

@@ -107,7 +107,11 @@ def main():
         ins = [x for b in blocks[j:i + 1] for x in b["ins"]]
         cls, sub, ops = summarise(ins)
         inner = [(a, c) for (a, c) in loops if j <= a and c <= i and (a, c) != (j, i)]
-        out["loops"].append({"head": blocks[j]["label"], "tail_block": blocks[i]["label"], "blocks": i - j + 1, "instructions": len(ins),
+        blist = []
+        for bb in blocks[j:i + 1]:
+            c2, s2, _ = summarise(bb["ins"])
+            blist.append({"label": bb["label"], "instructions": len(bb["ins"]), "classes": dict(c2), "valu_subclasses": dict(s2)})
+        out["loops"].append({"head": blocks[j]["label"], "tail_block": blocks[i]["label"], "blocks": i - j + 1, "instructions": len(ins), "block_list": blist,
                              "contains_loops": [blocks[a]["label"] for a, _ in inner], "classes": dict(cls), "valu_subclasses": dict(sub),
                              "opcodes": dict(ops.most_common())})
     if "--blocks" in sys.argv:

@@ -11,6 +11,11 @@
 // tile's rows to a fixed-order f64 reduction (the original: one fp32 atomic per pixel per component, non-deterministic).
 // render_fb_wave_kernel does forward and backward of the fused render-loss training step in a single pass.
 #include "u3d_common.h"
+#ifdef U3D_LPT_EXPERIMENT
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+#endif
 
 namespace {
 
@@ -616,12 +621,21 @@ __device__ __forceinline__ void store4(float* __restrict__ p, bool vec, const bo
 // magic multiplier (`tile_magic`, 0 = divide), so the prologue has no integer division.  Workgroups are dispatched to the XCDs
 // round-robin in linear order x + T * view, which is what u3d_xcd_chunk_in_view assumes.
 static_assert(TILE_WAVES == 1, "one wave = one workgroup = one tile");
+#ifdef U3D_LPT_EXPERIMENT   /* tools/lpt_tiles.sh: tiles dispatched in the order of a host-made permutation (cost of the previous, identical step) */
+__device__ uint32_t* g_lpt_perm = nullptr;
+__device__ uint32_t* g_lpt_cost = nullptr;
+#define U3D_LPT_MAP                                                                                     \
+  if (g_lpt_perm) { const uint32_t lin_ = g_lpt_perm[blockIdx.x + (uint32_t)T * view_u]; view_u = lin_ / (uint32_t)T; tile = (int)(lin_ - view_u * (uint32_t)T); }
+#else
+#define U3D_LPT_MAP
+#endif
 #define U3D_TILE_PROLOGUE(NWAVES)                                                                       \
   const int lane = threadIdx.x, wave = 0;                                                               \
-  const uint32_t view_u = blockIdx.y + gridDim.y * blockIdx.z;                                          \
+  uint32_t view_u = blockIdx.y + gridDim.y * blockIdx.z;                                                \
   if (view_u * (uint32_t)T >= ntiles_total) return; /* (partial last slab) */                           \
+  int tile = (int)u3d_xcd_chunk_in_view(blockIdx.x, view_u, (uint32_t)T);                               \
+  U3D_LPT_MAP                                                                                           \
   const int view = (int)view_u;                                                                         \
-  const int tile = (int)u3d_xcd_chunk_in_view(blockIdx.x, view_u, (uint32_t)T);                         \
   const uint32_t lid = view_u * (uint32_t)T + (uint32_t)tile;                                           \
   const int ty = tile_magic ? (int)__umulhi((uint32_t)tile, tile_magic) : tile / tiles_x;               \
   const int tx = tile - ty * tiles_x;                                                                   \
@@ -823,6 +837,9 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
   }
   e = u3d_wave_sum(e);
   if (lane == 0) loss.partial[lid] = e;
+#ifdef U3D_LPT_EXPERIMENT
+  if (lane == 0 && g_lpt_cost) g_lpt_cost[lid] = F.wlast;
+#endif
 
   if (plain)
     tile_backward<false, PB, true>(L, G, lane, F.wlast, F.staged, F.staged_bal, pyf, pxf, F.stop_pos, F.Tr, Rk, dp0, dp1, dp2, dinv,
@@ -1128,6 +1145,46 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
   uint32_t* tw = u3d_uses_touched_words(d) ? b.touched_words : nullptr;
   uint2* tl = (list_touched && tw) ? b.touched_list : nullptr;
   uint32_t* tc = (list_touched && tw) ? b.touched_count : nullptr;
+#ifdef U3D_LPT_EXPERIMENT
+  {
+    static int launches = 0;
+    static uint32_t *d_cost = nullptr, *d_perm = nullptr;
+    static const int mode = getenv("U3D_LPT_MODE") ? atoi(getenv("U3D_LPT_MODE")) : 0;   // 1 heavy first, 2 light first, 3 random (control), 4 heavy first within views interleaved
+    if (mode > 0 && u3d_part_blocks(d) == 1) {
+      ++launches;
+      if (launches == 1) {
+        (void)hipMalloc(&d_cost, sizeof(uint32_t) * ntiles); (void)hipMalloc(&d_perm, sizeof(uint32_t) * ntiles);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lpt_cost), &d_cost, sizeof(d_cost));
+      }
+      if (launches == 30) {
+        (void)hipStreamSynchronize(s);
+        std::vector<uint32_t> cost(ntiles), perm(ntiles);
+        (void)hipMemcpy(cost.data(), d_cost, sizeof(uint32_t) * ntiles, hipMemcpyDeviceToHost);
+        for (uint32_t i = 0; i < ntiles; ++i) perm[i] = i;
+        if (mode == 1) std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+        if (mode == 2) std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return cost[a] < cost[b]; });
+        if (mode == 3) { uint32_t st = 12345u; for (uint32_t i = ntiles - 1; i > 0; --i) { st = st * 1664525u + 1013904223u; std::swap(perm[i], perm[st % (i + 1)]); } }
+        if (mode == 4) {   // per view: its tiles heavy first; block b -> (view b % NV, rank b / NV): what a production form could compute per view
+          const uint32_t NV = ntiles / (uint32_t)T;
+          std::vector<uint32_t> within(ntiles);
+          for (uint32_t v = 0; v < NV; ++v) {
+            std::vector<uint32_t> t((size_t)T);
+            for (int j = 0; j < T; ++j) t[j] = v * (uint32_t)T + (uint32_t)j;
+            std::stable_sort(t.begin(), t.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+            for (int j = 0; j < T; ++j) within[v * (uint32_t)T + (uint32_t)j] = t[j];
+          }
+          for (uint32_t b2 = 0; b2 < ntiles; ++b2) perm[b2] = within[(b2 % NV) * (uint32_t)T + b2 / NV];
+        }
+        double mean = 0; uint32_t mx = 0; for (auto c2 : cost) { mean += c2; mx = c2 > mx ? c2 : mx; }
+        fprintf(stderr, "[lpt] mode %d: %u tiles, cost mean %.2f max %u; first %u last %u\n", mode, ntiles, mean / ntiles, mx, cost[perm[0]], cost[perm[ntiles - 1]]);
+        (void)hipMemcpy(d_perm, perm.data(), sizeof(uint32_t) * ntiles, hipMemcpyHostToDevice);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lpt_perm), &d_perm, sizeof(d_perm));
+        uint32_t* nul = nullptr;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lpt_cost), &nul, sizeof(nul));
+      }
+    }
+  }
+#endif
   if (u3d_part_blocks(d) == 1)
     hipLaunchKernelGGL(render_fb_wave_kernel<1>, tg.grid, dim3(TILE_WAVES * U3D_WAVE), 0, s, u3d_span(d), d.image_height, d.image_width,
                        tiles_x, T, ntiles, tg.magic, NG, b.sorted_id, u3d_rect_indirect(d) ? b.rect : b.sorted_rect, u3d_rect_indirect(d), b.n_vis, b.xy, b.conic_op, b.rgbd, bg, out_color,
