@@ -138,6 +138,10 @@ def test_default_line_carries_the_other_configs_and_the_noop_control():
     assert set(ex["other_configs"]) == {"C3", "C4", "C5", "C2_compact", "C4_fused", "C5_fused"} and len(ex["pointops_us"]) >= 14
     assert ex["per_view"]["operator_gpu_ms"] > 0 and ex["per_view"]["operator_host_ms"] > 0
     assert line["roofline"]["kernel"] == "render_fb" and line["roofline"]["traffic"] and line["roofline"]["frac_consumed"] > 0
+    assert line["roofline"]["traffic_source"].startswith("profiles/r06/")                   # this round's committed PMC pass
+    # the tile kernel's issue floors, none fitted to it: every VALU at the guide's 2 cycles < transcendentals at quarter rate < measured opcode costs <= 1
+    iss = ex["issue"]
+    assert 0 < iss["frac_valu_2cyc"] < iss["frac_valu_trans_quarter"] < iss["frac_opcode_costs"] <= 1.0 and 0.5 < iss["wave_slot_occupancy"] <= 1.0
     assert line["scale_verdict"].startswith("n/a")
     oc = out["other_configs"]
     for k in ("C3", "C4", "C5", "C2_compact", "C4_fused", "C5_fused"):
