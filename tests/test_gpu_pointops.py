@@ -144,6 +144,22 @@ def test_gradient_kernels_beyond_the_lds_rows():
         assert np.abs(f.grad.cpu().numpy() - gref).max() <= 1e-5 * max(np.abs(gref).max(), 1.0)
 
 
+@pytest.mark.parametrize("N", [64, 100, 128, 130, 256, 300, 511, 512])
+def test_fps_one_wave_per_cloud_ties_and_sizes(N):
+    """Round 6: clouds of up to 512 points run as ONE wave (2 / 4 / 8 points per lane).  Its common path takes the holder of the maximum from a vector
+    count; exact ties -- every point duplicated, so that two points sit at EVERY distance, and a lattice -- must fall back to the reference's tie order.
+    Bit-identical selections against the oracle for every size class and its edges."""
+    from unipre3d_amd import pointops
+    rng = np.random.RandomState(N)
+    half = rng.randn(2, (N + 1) // 2, 3).astype(np.float32)
+    dup = np.concatenate([half, half], axis=1)[:, :N]                      # point k and k + ceil(N/2) coincide
+    lattice = _cloud(2, N, seed=N + 7, grid=True)
+    plain = _cloud(2, N, seed=N + 9)
+    for xyz, M in ((dup, min(N, 48)), (lattice, min(N, 64)), (plain, N)):
+        got = pointops.furthest_point_sample(torch.from_numpy(np.ascontiguousarray(xyz)).cuda(), M).cpu().numpy()
+        assert np.array_equal(got, po.furthest_point_sampling(np.ascontiguousarray(xyz), M)), (N, M)
+
+
 def test_fps_degenerate_clouds():
     """All points identical (every distance 0: the tie key alone decides, padding slots must never win), more samples than points,
     and sizes straddling every register-slot configuration of the kernel."""

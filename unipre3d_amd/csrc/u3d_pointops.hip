@@ -161,15 +161,19 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int lg, 
     }
     const uint32_t wmax = wave_max_u32(lmax);
     uint32_t btk = 0u;                               // largest inverted tie key among this wave's points at distance wmax
+    // (round 6 tried the single-wave kernel's vector count here -- one tie key on the scalar unit when exactly one point of the wave is at its maximum:
+    //  +3 % at 2048 points, +4.5 % at 8192: with several waves per SIMD the per-slot ballots hide behind the other waves, the extra VALU work does not)
+    {
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {                  // (all compares first + one combined test measured slower: 61 vs 56 us at 1024 -> 128)
-      unsigned long long mk = __ballot(t[i] == wmax);
-      while (mk) {
-        const uint32_t k = wave_base + (uint32_t)__builtin_ctzll(mk) + (uint32_t)(i * FPS_THREADS);
-        mk &= mk - 1ull;
-        if (k < (uint32_t)n) {
-          const uint32_t tk = ~fps_tie_key(k, lg, bs);
-          btk = tk > btk ? tk : btk;
+      for (int i = 0; i < PPT; ++i) {                // (all compares first + one combined test measured slower: 61 vs 56 us at 1024 -> 128)
+        unsigned long long mk = __ballot(t[i] == wmax);
+        while (mk) {
+          const uint32_t k = wave_base + (uint32_t)__builtin_ctzll(mk) + (uint32_t)(i * FPS_THREADS);
+          mk &= mk - 1ull;
+          if (k < (uint32_t)n) {
+            const uint32_t tk = ~fps_tie_key(k, lg, bs);
+            btk = tk > btk ? tk : btk;
+          }
         }
       }
     }
@@ -181,6 +185,77 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int lg, 
     if (tid == 0) out[j] = old;
     cur = nxt;
     nxt = nxt == 2 ? 0 : nxt + 1;
+  }
+}
+
+// Round 6: ONE WAVE per cloud (n <= 64 * PPT).  A selection of the multi-wave kernel above is ~45 instructions and ~950 clocks: most of it the
+// waves meeting -- an LDS atomic, a barrier, the read back -- not arithmetic.  A lone wave needs none of that: the wave maximum and the winner's tie key are
+// already wave-uniform (SGPRs) after the DPP reduction and the per-slot ballots, so the next centre is decoded on the scalar unit and its coordinates come
+// from one broadcast LDS read.  The price is PPT points per lane in the distance scan (independent chains: they pipeline), which is why more points per lane
+// LOST in the multi-wave form (128 threads: +18 %) and wins here.  Same distances, same tie order: bit-identical selections.
+template <int PPT, int CM>
+__global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int lg, const float* __restrict__ dataset, int32_t* __restrict__ idxs) {
+  extern __shared__ __attribute__((aligned(16))) float s_xyz[];   // [n][3]
+  const int bi = blockIdx.x, lane = threadIdx.x;
+  const float* ds = dataset + (size_t)bi * n * 3;
+  int32_t* out = idxs + (size_t)bi * m;
+  for (int i = lane; i < n * 3; i += 64) s_xyz[i] = ds[i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t bs = 1u << lg;
+  float x[PPT], y[PPT], z[PPT];
+  uint32_t t[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = lane + i * 64;
+    const bool v = k < n;
+    x[i] = v ? s_xyz[k * 3] : 0.f; y[i] = v ? s_xyz[k * 3 + 1] : 0.f; z[i] = v ? s_xyz[k * 3 + 2] : 0.f;
+    t[i] = v ? __float_as_uint(1e10f) : 0u;          // padding slots: distance 0, and never a candidate below (k >= n)
+  }
+  int old = 0;
+  if (lane == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float ox = s_xyz[old * 3], oy = s_xyz[old * 3 + 1], oz = s_xyz[old * 3 + 2];
+    uint32_t lmax = 0u;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      t[i] = min(t[i], __float_as_uint(dist2<CM>(ox, oy, oz, x[i], y[i], z[i])));
+      lmax = max(lmax, t[i]);
+    }
+    const uint32_t wmax = wave_max_u32(lmax);
+    // WHICH point holds the maximum.  Equal distances are rare, so the common case is decided on the vector unit: every lane counts its slots at
+    // the maximum and remembers one of them (compare + select + add per slot, pipelined -- a scalar ballot-and-branch per slot costs ~56 clocks of a lone
+    // wave's time each); one ballot then says whether exactly ONE point of the cloud is at the maximum, and if so its index is lane + 64 slot -- no
+    // tie key at all.  Only a genuine tie walks the slots' ballots for the reference's tie order.
+    uint32_t cnt = 0u, slot = 0u;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const bool e = t[i] == wmax;
+      cnt += e ? 1u : 0u;
+      slot = e ? (uint32_t)i : slot;
+    }
+    const unsigned long long has = __ballot(cnt != 0u), many = __ballot(cnt > 1u);
+    const uint32_t L = (uint32_t)__builtin_ctzll(has);
+    const uint32_t k1 = L + 64u * (uint32_t)__builtin_amdgcn_readlane((int)slot, (int)L);
+    if (many == 0ull && (has & (has - 1ull)) == 0ull && k1 < (uint32_t)n) {
+      old = (int)k1;
+    } else {
+      uint32_t btk = 0u;                             // largest inverted tie key among the points at distance wmax
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        unsigned long long mk = __ballot(t[i] == wmax);
+        while (mk) {
+          const uint32_t k = (uint32_t)__builtin_ctzll(mk) + (uint32_t)(i * 64);
+          mk &= mk - 1ull;
+          if (k < (uint32_t)n) {
+            const uint32_t tk = ~fps_tie_key(k, lg, bs);
+            btk = tk > btk ? tk : btk;
+          }
+        }
+      }
+      old = fps_decode(~btk, lg);
+    }
+    if (lane == 0) out[j] = old;
   }
 }
 
@@ -682,6 +757,22 @@ int u3d_furthest_point_sampling(int b, int n, int m, const float* points, float*
   // small clouds: U3D_FPS_SMALL_THREADS / 64 waves keep the per-selection chain short; larger ones spread over U3D_FPS_BIG_THREADS / 64
   constexpr int ST = U3D_FPS_SMALL_THREADS, BT = U3D_FPS_BIG_THREADS;
   bool big_lds_refused = false;
+  // one wave per cloud up to 512 points (measured, us per selection, one wave / multi-wave: 256 points 0.273 / 0.393, 512: 0.329 / 0.391, 1024: 0.46 - 0.485 /
+  // 0.42 - 0.44, 2048: 0.98 / 0.50: a lone wave issues one VALU instruction per ~3 clocks, 11 per point and selection).  U3D_FPS_WAVE_MAX: experiment switch
+  static const int wave_max = getenv("U3D_FPS_WAVE_MAX") ? atoi(getenv("U3D_FPS_WAVE_MAX")) : 512;
+#define FPSW(P)                                                                                                        \
+  do {                                                                                                                 \
+    if (g_contraction == U3D_PO_FMA_LLVM) hipLaunchKernelGGL((fps_wave_kernel<P, U3D_PO_FMA_LLVM>), dim3(b), dim3(64), lds, s, n, m, lg, points, idx);        \
+    else if (g_contraction == U3D_PO_FMA_CHAIN) hipLaunchKernelGGL((fps_wave_kernel<P, U3D_PO_FMA_CHAIN>), dim3(b), dim3(64), lds, s, n, m, lg, points, idx); \
+    else hipLaunchKernelGGL((fps_wave_kernel<P, U3D_PO_NO_FMA>), dim3(b), dim3(64), lds, s, n, m, lg, points, idx);    \
+  } while (0)
+  if (n <= wave_max && n <= 2048) {
+    if (n <= 128) FPSW(2);
+    else if (n <= 256) FPSW(4);
+    else if (n <= 512) FPSW(8);
+    else if (n <= 1024) FPSW(16);
+    else FPSW(32);
+  } else
   if (n <= 256) FPS(256, 1);
   else if (n <= 512) FPS(ST, 512 / ST);
   else if (n <= 1024) FPS(ST, 1024 / ST);
@@ -694,6 +785,7 @@ int u3d_furthest_point_sampling(int b, int n, int m, const float* points, float*
   }
 #undef FPS
 #undef FPS_CM
+#undef FPSW
   if (big_lds_refused) {
     if (!temp) return 3;
     U3D_PO_LAUNCH_CM(fps_kernel_large, dim3(b), dim3(1024), 0, s, n, m, lg, points, temp, idx);
