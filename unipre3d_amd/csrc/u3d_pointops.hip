@@ -188,6 +188,11 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int lg, 
   }
 }
 
+// (Round 6 also rebuilt the multi-wave selection around `tools/ub/fps_phases.hip`'s stamps -- centre read from LDS ~200 clocks, scan ~210, wave maximum ~150,
+//  holder search ~350, atomic ~190, barrier ~95 (660 with 16 waves), read back + decode ~260 --: per-lane running (maximum, slot, coordinates) in the scan so that one
+//  ballot and v_readlanes replace the per-slot search, every wave's candidate coordinates posted beside its key so that the next centre needs ONE LDS round trip after
+//  the barrier instead of two.  Bit-identical selections, and SLOWER: 1024 points 0.445 -> 0.578 us per selection, 2048: 0.498 -> 0.616, 8192: 0.753 -> 1.236.  The
+//  selects ride on the scan's dependent chain and the scalar lane reads serialise behind the wave maximum; the stamped phases overstate what the search costs.)
 // Round 6: ONE WAVE per cloud (n <= 64 * PPT).  A selection of the multi-wave kernel above is ~45 instructions and ~950 clocks: most of it the
 // waves meeting -- an LDS atomic, a barrier, the read back -- not arithmetic.  A lone wave needs none of that: the wave maximum and the winner's tie key are
 // already wave-uniform (SGPRs) after the DPP reduction and the per-slot ballots, so the next centre is decoded on the scalar unit and its coordinates come
