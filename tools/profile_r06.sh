@@ -110,7 +110,7 @@ d = {"command": f"rocprofv3 --pmc <two passes> --kernel-trace -- python bench.py
      "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE sums the 8 XCDs"}
 if cyc and per.get("SQ_WAVE_CYCLES"):
     wc = per["SQ_WAVE_CYCLES"]
-    d["derived"] = {"shader_cycles_per_launch": cyc, "wave_slot_occupancy": 4.0 * wc / (cyc * 8192.0),
+    d["derived"] = {"shader_cycles_per_launch": cyc, "wave_slot_occupancy": 4.0 * wc / (cyc * 7168.0), "wave_slots": 7168,
                     "share_of_wave_time_waiting_for_issue": per.get("SQ_WAIT_INST_ANY", 0.0) / wc, "share_of_wave_time_in_s_waitcnt": per.get("SQ_WAIT_ANY", 0.0) / wc,
                     "share_of_wave_time_issuing": per.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, "lds_pipeline_busy_share_per_cu": per.get("SQ_LDS_IDX_ACTIVE", 0.0) / 256.0 / cyc,
                     "cycles_per_valu_instruction_per_simd": cyc * 1024.0 / per["SQ_INSTS_VALU"] if per.get("SQ_INSTS_VALU") else None}

@@ -606,14 +606,16 @@ __device__ __forceinline__ void store4(float* __restrict__ p, bool vec, const bo
 }
 
 // The tile kernels carry two loop variants each (PLAIN and not); left alone, the register allocator takes 75-77 VGPRs for the pair
-// (6 waves per SIMD).  For the single-pass kernel, pinning 8 waves per SIMD (64 VGPRs) spills a handful of values around the rarely
-// taken variant and measured 3 % faster than the unpinned build, 4.5 % faster than the single-variant kernel; the two-pass kernels
-// measured slower pinned (forward 97 against 87 us at C2) and are left to the allocator.
+// (6 waves per SIMD).  The single-pass kernel is PINNED: round 4 measured 8 waves per SIMD (64 VGPRs, a handful of values spilled around the rarely
+// taken variant) 3 % ahead of the unpinned build; with round 5's alpha_run and round 6's forward the optimum moved to 7 (72 VGPRs, fewer spills):
+// render_fb scope, pins 8 / 7 / 6 / none on one box, two rounds: C2 176.0 / 173.2 - 173.7 / 176.1 - 176.3 / 177.2 - 177.5 us, C3 91.8 - 92.4 / 90.5 - 91.0 /
+// 92.1 - 92.2 / 92.3, C5 103.3 - 103.8 / 101.4 - 101.5 / 100.7 - 101.0 / 101.0 - 101.5.  The two-pass kernels measured slower pinned (forward 97 against
+// 87 us at C2) and are left to the allocator.
 #ifdef U3D_NO_OCC_PIN   /* tools/pmc_spill_probe.sh: the unpinned build, to attribute the scratch-spill share of the kernel's HBM writes */
 #define U3D_FULL_OCCUPANCY
 #else
 #ifndef U3D_OCC_PIN
-#define U3D_OCC_PIN 8
+#define U3D_OCC_PIN 7
 #endif
 #define U3D_FULL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(U3D_OCC_PIN, U3D_OCC_PIN)))
 #endif
