@@ -85,9 +85,12 @@ out = {
             "cycles": body_cycles + overhead_valu * 2.4 / 1024.0,
             "frac": (body_cycles + overhead_valu * 2.4 / 1024.0) / cycles,
             "note": "loop bodies at their opcode costs + the per-tile remainder at the bodies' mean VALU cost (2.4 cycles)"},
-        "reading": "no build of THIS instruction mix can run below the opcode-cost floor.  What separates the kernel from it: the %d wave slots (7 per SIMD) are occupied "
-                   "%.2f of the launch (SQ_WAVE_CYCLES x 4 / (cycles x slots), profiles/r06/sq_wait_C2.json) -- dispatching the tiles heaviest-first moves the kernel " % (SW.get("wave_slots", 7168), SW.get("wave_slot_occupancy", float("nan"))) +
-                   "by -2 %, lightest-first by +3 %, a persistent-wave form with a software dequeue by +30 % (EXPERIMENTS.md, round 6) -- and inside a resident wave "
-                   "%.0f %% of the time is spent waiting for an issue slot or a dependency, %.0f %% in s_waitcnt on LDS round trips" % (100 * SW.get("share_of_wave_time_waiting_for_issue", float("nan")), 100 * SW.get("share_of_wave_time_in_s_waitcnt", float("nan")))},
+        "reading": ("no build of THIS instruction mix can run below the opcode-cost floor.  What separates the kernel from it: the {slots} wave slots (7 per SIMD) are occupied "
+                    "{occ:.2f} of the launch (SQ_WAVE_CYCLES x 4 / (cycles x slots), profiles/r06/sq_wait_C2.json) -- dispatching the tiles heaviest-first moves the kernel "
+                    "by -2 %, lightest-first by +3 %, a persistent-wave form with a software dequeue by +30 % (EXPERIMENTS.md, round 6) -- and inside a resident wave "
+                    "{wi:.0f} % of the time is spent waiting for an issue slot or a dependency, {ww:.0f} % in s_waitcnt on LDS round trips").format(
+                        slots=SW.get("wave_slots", 7168), occ=SW.get("wave_slot_occupancy", float("nan")), wi=100 * SW.get("share_of_wave_time_waiting_for_issue", float("nan")),
+                        ww=100 * SW.get("share_of_wave_time_in_s_waitcnt", float("nan")))
+    },
 }
 print(json.dumps(out, indent=1))
