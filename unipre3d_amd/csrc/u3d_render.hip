@@ -11,7 +11,7 @@
 // tile's rows to a fixed-order f64 reduction (the original: one fp32 atomic per pixel per component, non-deterministic).
 // render_fb_wave_kernel does forward and backward of the fused render-loss training step in a single pass.
 #include "u3d_common.h"
-#ifdef U3D_LPT_EXPERIMENT
+#if defined(U3D_LPT_EXPERIMENT) || defined(U3D_TIMELINE)
 #include <algorithm>
 #include <cstdio>
 #include <vector>
@@ -631,6 +631,9 @@ __device__ uint32_t* g_lpt_cost = nullptr;
 #else
 #define U3D_LPT_MAP
 #endif
+#ifdef U3D_TIMELINE   /* tools/tile_timeline.sh: when and where (XCD, CU, SIMD, wave slot) every tile of a launch ran */
+__device__ uint4* g_timeline = nullptr;
+#endif
 #define U3D_TILE_PROLOGUE(NWAVES)                                                                       \
   const int lane = threadIdx.x, wave = 0;                                                               \
   uint32_t view_u = blockIdx.y + gridDim.y * blockIdx.z;                                                \
@@ -802,6 +805,9 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
   __shared__ float4 sP0[TILE_WAVES][U3D_WAVE], sP1[TILE_WAVES][U3D_WAVE];
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ __attribute__((aligned(8))) float sAcc[TILE_WAVES][U3D_WAVE][10];
+#ifdef U3D_TIMELINE
+  const uint64_t tl_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   U3D_TILE_PROLOGUE(TILE_WAVES);
   const TileLds L{sP0[wave], sP1[wave], sP2[wave], nullptr, sAcc[wave], &sAcc[wave][0][9], 10};
 #pragma unroll
@@ -851,6 +857,14 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
     tile_backward<false, PB, false>(L, G, lane, F.wlast, F.staged, F.staged_bal, pyf, pxf, F.stop_pos, F.Tr, Rk, dp0, dp1, dp2, dinv,
                        0.5f * (float)W, 0.5f * (float)H, NG, acc, part + (size_t)lid * (PB * U3D_WAVE * 10),
                           reinterpret_cast<uint32_t*>(part + (size_t)ntiles_total * BWD_PART_STRIDE) + lid);
+#ifdef U3D_TIMELINE
+  if (lane == 0 && g_timeline) {
+    const uint64_t tl_t1 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one counter for the whole device
+    // HW_ID (register 4): wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13];  XCC_ID (register 20): [3:0]
+    g_timeline[lid] = make_uint4((uint32_t)tl_t0, (uint32_t)tl_t1, __builtin_amdgcn_s_getreg((31 << 11) | 4),
+                                 (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) | (F.wlast << 4));
+  }
+#endif
 }
 
 // acc[k][view*P + sorted_id[sp]] += sum over a slice of the view's tiles (ascending) of part[tile][sp][k], in f64;
@@ -1183,6 +1197,30 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lpt_perm), &d_perm, sizeof(d_perm));
         uint32_t* nul = nullptr;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lpt_cost), &nul, sizeof(nul));
+      }
+    }
+  }
+#endif
+#ifdef U3D_TIMELINE
+  {
+    static int launches = 0;
+    static uint4* d_tl = nullptr;
+    static const char* out = getenv("U3D_TIMELINE_OUT");
+    if (out) {
+      ++launches;
+      if (launches == 30) {   // record the 30th launch
+        (void)hipMalloc(&d_tl, sizeof(uint4) * ntiles);
+        (void)hipMemset(d_tl, 0, sizeof(uint4) * ntiles);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &d_tl, sizeof(d_tl));
+      }
+      if (launches == 31) {
+        (void)hipStreamSynchronize(s);
+        std::vector<uint4> h(ntiles);
+        (void)hipMemcpy(h.data(), d_tl, sizeof(uint4) * ntiles, hipMemcpyDeviceToHost);
+        uint4* nul = nullptr;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &nul, sizeof(nul));
+        if (FILE* f = fopen(out, "wb")) { fwrite(h.data(), sizeof(uint4), ntiles, f); fclose(f); }
+        fprintf(stderr, "[timeline] %u tiles of launch 30 -> %s\n", ntiles, out);
       }
     }
   }
