@@ -12,13 +12,12 @@ import numpy as np
 
 
 def main(path, cap=7):
-    a = np.fromfile(path, dtype=np.uint32).reshape(-1, 4)
+    a = np.fromfile(path, dtype=np.uint32).reshape(-1, 8)
+    a = a[a[:, 1] != 0]
     t0, t1, hw, x = a[:, 0].astype(np.int64), a[:, 1].astype(np.int64), a[:, 2], a[:, 3]
-    ok = t1 != 0
-    t0, t1, hw, x = t0[ok], t1[ok], hw[ok], x[ok]
-    t1 = np.where(t1 < t0, t1 + (1 << 32), t1)
+    ta, tb, clk = a[:, 4].astype(np.int64), a[:, 5].astype(np.int64), a[:, 6].astype(np.float64)
     base = t0.min()
-    t0, t1 = (t0 - base) * 0.01, (t1 - base) * 0.01           # us
+    t0, t1, ta, tb = [((v - base) % (1 << 32)) * 0.01 for v in (t0, t1, ta, tb)]   # us
     span = float(t1.max())
     xcc, walk = (x & 15).astype(np.int64), (x >> 4).astype(np.int64)
     simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
@@ -65,6 +64,11 @@ def main(path, cap=7):
         "duration_fit_us": {"fixed_per_tile": round(float(coef[0]), 3), "per_walked_entry": round(float(coef[1]), 4),
                             "fixed_share_of_wave_time": round(float(coef[0] * len(dur) / dur.sum()), 3)},
         "last_exit_per_xcc_us": per_xcc,
+        "shader_clock_ghz": {"all": round(float(clk.sum() / dur.sum()) * 1e-3, 3), "first_round": round(float(clk[t0 < 1].sum() / dur[t0 < 1].sum()) * 1e-3, 3),
+                             "started_after_20us": round(float(clk[t0 > 20].sum() / dur[t0 > 20].sum()) * 1e-3, 3)},
+        "phases_us": {name: {"forward_walk_incl_staging": round(float((ta - t0)[m].mean()), 2), "loss_epilogue": round(float((tb - ta)[m].mean()), 2),
+                             "backward_walk_incl_publish": round(float((t1 - tb)[m].mean()), 2), "walk": round(float(walk[m].mean()), 2), "tiles": int(m.sum())}
+                      for name, m in (("first_round", t0 < 1), ("started_5_to_100us", (t0 > 5) & (t0 < 100)), ("started_in_the_tail", t0 > np.median(last_full))) if m.any()},
         "entries_per_10us": " ".join(str(int(v)) for v in np.histogram(t0, bins=np.arange(0, span + 10, 10))[0]),
         "exits_per_10us": " ".join(str(int(v)) for v in np.histogram(t1, bins=np.arange(0, span + 10, 10))[0]),
     }

@@ -632,7 +632,7 @@ __device__ uint32_t* g_lpt_cost = nullptr;
 #define U3D_LPT_MAP
 #endif
 #ifdef U3D_TIMELINE   /* tools/tile_timeline.sh: when and where (XCD, CU, SIMD, wave slot) every tile of a launch ran */
-__device__ uint4* g_timeline = nullptr;
+__device__ uint4* g_timeline = nullptr;   // two uint4 per tile
 #endif
 #define U3D_TILE_PROLOGUE(NWAVES)                                                                       \
   const int lane = threadIdx.x, wave = 0;                                                               \
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
   __shared__ float2 sP2[TILE_WAVES][U3D_WAVE];
   __shared__ __attribute__((aligned(8))) float sAcc[TILE_WAVES][U3D_WAVE][10];
 #ifdef U3D_TIMELINE
-  const uint64_t tl_t0 = __builtin_amdgcn_s_memrealtime();
+  const uint64_t tl_t0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime();
 #endif
   U3D_TILE_PROLOGUE(TILE_WAVES);
   const TileLds L{sP0[wave], sP1[wave], sP2[wave], nullptr, sAcc[wave], &sAcc[wave][0][9], 10};
@@ -816,6 +816,9 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
   const uint32_t nv = n_vis[view];
   const bool plain = tile_forward<false, true>(L, G, lane, nv, pyf, pxf, inside, F);
   if (!plain) tile_forward<false, false>(L, G, lane, nv, pyf, pxf, inside, F);
+#ifdef U3D_TIMELINE
+  const uint64_t tl_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // loss term, dL/dcolor seed
   float dp0[4], dp1[4], dp2[4], dinv[4], Rk[4], o0[4], o1[4], o2[4], g0[4], g1[4], g2[4];
@@ -848,6 +851,9 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
 #ifdef U3D_LPT_EXPERIMENT
   if (lane == 0 && g_lpt_cost) g_lpt_cost[lid] = F.wlast;
 #endif
+#ifdef U3D_TIMELINE
+  const uint64_t tl_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   if (plain)
     tile_backward<false, PB, true>(L, G, lane, F.wlast, F.staged, F.staged_bal, pyf, pxf, F.stop_pos, F.Tr, Rk, dp0, dp1, dp2, dinv,
@@ -859,10 +865,13 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
                           reinterpret_cast<uint32_t*>(part + (size_t)ntiles_total * BWD_PART_STRIDE) + lid);
 #ifdef U3D_TIMELINE
   if (lane == 0 && g_timeline) {
-    const uint64_t tl_t1 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one counter for the whole device
+    const uint64_t tl_t3 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one counter for the whole device
+    const uint64_t tl_c1 = __builtin_amdgcn_s_memtime();       // shader clock
     // HW_ID (register 4): wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13];  XCC_ID (register 20): [3:0]
-    g_timeline[lid] = make_uint4((uint32_t)tl_t0, (uint32_t)tl_t1, __builtin_amdgcn_s_getreg((31 << 11) | 4),
-                                 (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) | (F.wlast << 4));
+    g_timeline[2 * (size_t)lid] = make_uint4((uint32_t)tl_t0, (uint32_t)tl_t3, __builtin_amdgcn_s_getreg((31 << 11) | 4),
+                                             (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) | (F.wlast << 4));
+    // after the forward walk, after the loss epilogue, shader clocks between entry and exit
+    g_timeline[2 * (size_t)lid + 1] = make_uint4((uint32_t)tl_t1, (uint32_t)tl_t2, (uint32_t)(tl_c1 - tl_c0), plain ? 1u : 0u);
   }
 #endif
 }
@@ -1206,21 +1215,22 @@ void u3d_launch_render_fb(const u3d_raster_desc& d, const U3DBuffers& b, const f
     static int launches = 0;
     static uint4* d_tl = nullptr;
     static const char* out = getenv("U3D_TIMELINE_OUT");
+    static const int at = getenv("U3D_TIMELINE_AT") ? atoi(getenv("U3D_TIMELINE_AT")) : 150;   // (the first ~100 launches of a process run below the operating clock)
     if (out) {
       ++launches;
-      if (launches == 30) {   // record the 30th launch
-        (void)hipMalloc(&d_tl, sizeof(uint4) * ntiles);
-        (void)hipMemset(d_tl, 0, sizeof(uint4) * ntiles);
+      if (launches == at) {   // launches at .. at + 5 record (back to back with their steps); the last one is kept
+        (void)hipMalloc(&d_tl, 2 * sizeof(uint4) * ntiles);
+        (void)hipMemset(d_tl, 0, 2 * sizeof(uint4) * ntiles);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &d_tl, sizeof(d_tl));
       }
-      if (launches == 31) {
+      if (launches == at + 6) {
         (void)hipStreamSynchronize(s);
-        std::vector<uint4> h(ntiles);
-        (void)hipMemcpy(h.data(), d_tl, sizeof(uint4) * ntiles, hipMemcpyDeviceToHost);
+        std::vector<uint4> h(2 * (size_t)ntiles);
+        (void)hipMemcpy(h.data(), d_tl, 2 * sizeof(uint4) * ntiles, hipMemcpyDeviceToHost);
         uint4* nul = nullptr;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &nul, sizeof(nul));
-        if (FILE* f = fopen(out, "wb")) { fwrite(h.data(), sizeof(uint4), ntiles, f); fclose(f); }
-        fprintf(stderr, "[timeline] %u tiles of launch 30 -> %s\n", ntiles, out);
+        if (FILE* f = fopen(out, "wb")) { fwrite(h.data(), sizeof(uint4), 2 * (size_t)ntiles, f); fclose(f); }
+        fprintf(stderr, "[timeline] %u tiles of launch %d -> %s\n", ntiles, at + 5, out);
       }
     }
   }
