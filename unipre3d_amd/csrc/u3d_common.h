@@ -299,7 +299,18 @@ __device__ __forceinline__ uint32_t u3d_xcd_remap(uint32_t bid, uint32_t nblocks
 // level) while neighbouring tiles -- which share image cache lines and the view's Gaussian state -- still meet in one L2.
 // Bijective on [0, nviews*T) for any T: block b sits on XCD b % 8; within view v (blocks [vT, vT+T)) the blocks of residue
 // class x are numbered in order and mapped to the x-th chunk of the view's tile range.
-__device__ __forceinline__ uint32_t u3d_xcd_chunk_in_view(uint32_t j, uint32_t view, uint32_t T) {   // tile (within the view) of block j
+// Round 6 (tools/tile_timeline.sh): with the same chunk of EVERY view on the same XCD, an XCD owns one image region -- at object level the top and
+// bottom rows walk 5 % more entries than the centre, and the two XCDs that own them finished 7.5 us after the first (152 .. 159 us).  When the
+// chunks are equal (T % 8 == 0) the chunk an XCD takes rotates with `rot` (the tile kernels pass the view at object level, P <= 256: C2 render_fb
+// scope 174.1 -> 171.2 us in five alternating pairs; 0 at scene level, where the rotation measured +0.2 ... +1.7 us on C3 / C4 / C5), so every XCD
+// sees every region: U3D_XCD_ROTATE (0 = round 5's map).
+#ifndef U3D_XCD_ROTATE
+#define U3D_XCD_ROTATE 1
+#endif
+__device__ __forceinline__ uint32_t u3d_xcd_chunk_in_view(uint32_t j, uint32_t view, uint32_t T, uint32_t rot = 0u) {   // tile (within the view) of block j
+#if U3D_XCD_ROTATE
+  if ((T & 7u) == 0u) return (((j + rot) & 7u) * (T >> 3)) + (j >> 3);   // block j sits on XCD j % 8 (view * T is a multiple of 8)
+#endif
   const uint32_t r = (view * T) & 7u, m = r + j, x = m & 7u;
   auto below = [](uint32_t n, uint32_t c) { return (n >> 3) * c + min(n & 7u, c); };   // #{i < n : i % 8 < c}
   const uint32_t k = ((m + 7u - x) >> 3) - ((r + 7u - x) >> 3);                         // rank of this block in its class

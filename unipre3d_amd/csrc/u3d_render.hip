@@ -638,7 +638,7 @@ __device__ uint4* g_timeline = nullptr;   // two uint4 per tile
   const int lane = threadIdx.x, wave = 0;                                                               \
   uint32_t view_u = blockIdx.y + gridDim.y * blockIdx.z;                                                \
   if (view_u * (uint32_t)T >= ntiles_total) return; /* (partial last slab) */                           \
-  int tile = (int)u3d_xcd_chunk_in_view(blockIdx.x, view_u, (uint32_t)T);                               \
+  int tile = (int)u3d_xcd_chunk_in_view(blockIdx.x, view_u, (uint32_t)T, span.P <= 256 ? view_u : 0u);  \
   U3D_LPT_MAP                                                                                           \
   const int view = (int)view_u;                                                                         \
   const uint32_t lid = view_u * (uint32_t)T + (uint32_t)tile;                                           \
@@ -808,6 +808,9 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
 #ifdef U3D_TIMELINE
   const uint64_t tl_t0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef U3D_PRIO_FWD
+  __builtin_amdgcn_s_setprio(U3D_PRIO_FWD);
+#endif
   U3D_TILE_PROLOGUE(TILE_WAVES);
   const TileLds L{sP0[wave], sP1[wave], sP2[wave], nullptr, sAcc[wave], &sAcc[wave][0][9], 10};
 #pragma unroll
@@ -853,6 +856,9 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_FULL_OCCUPANCY void rend
 #endif
 #ifdef U3D_TIMELINE
   const uint64_t tl_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef U3D_PRIO_BWD
+  __builtin_amdgcn_s_setprio(U3D_PRIO_BWD);
 #endif
 
   if (plain)
