@@ -122,6 +122,9 @@ constexpr int BWD_PART_STRIDE = U3D_PART_STRIDE;   // floats per tile: [U3D_PART
 // slice is latency-bound (cost ~ tiles per slice): ~128 tiles per slice measured best (C2: 10.4 us with 2 slices, 17 with 8).
 // With few views (scene level: 8-16) that alone leaves most CUs idle, so the slice count also grows until ~256 workgroups exist.
 static inline int bwd_reduce_split(int T, int NV) {
+#ifdef U3D_REDUCE_SPLIT_ENV   /* experiment builds: slices per view from the environment */
+  if (const char* e = getenv("U3D_REDUCE_SPLIT")) { const int v = atoi(e); if (v > 0 && v <= 32 && v <= T) return v; }
+#endif
   int s = (T + 64) / 128;
   const int fill = NV > 0 ? 256 / NV : 1;
   if (s < fill) s = fill;
