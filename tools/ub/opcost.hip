@@ -34,6 +34,41 @@
 #define LAD(i) "v_cmp_ge_f32_e64 s[26:27], %" #i ", %8\n" "s_and_b64 s[24:25], s[26:27], s[28:29]\n" "v_cndmask_b32_e64 %" #i ", 0, %" #i ", s[24:25]\n"
 #define CLOB : "vcc", "scc", "s20", "s21", "s24", "s25", "s26", "s27", "s30", "s31", "v40", "v41", "v42", "v43", "memory"
 
+// packed fp32 (v_pk_*_f32: two fp32 operations per lane in one instruction, operands in aligned register pairs)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int OP>
+__global__ __launch_bounds__(256) void kpk(float* out, float a, float b, int iters) {
+  f32x2 x0 = {(float)threadIdx.x, 1.f}, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f, x4 = x0 + 4.f, x5 = x0 + 5.f, x6 = x0 + 6.f, x7 = x0 + 7.f;
+  const f32x2 pa = {a, a}, pb = {b, b};
+#define PKARGS : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(pa), "v"(pb)
+#define PKFMA(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9\n"
+#define PKMUL(i) "v_pk_mul_f32 %" #i ", %" #i ", %8\n"
+#define PKADD(i) "v_pk_add_f32 %" #i ", %" #i ", %8\n"
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (OP == 0) asm volatile(OP8(PKFMA) PKARGS);
+      if (OP == 1) asm volatile(OP8(PKMUL) PKARGS);
+      if (OP == 2) asm volatile(OP8(PKADD) PKARGS);
+    }
+  }
+  const f32x2 t = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+  out[blockIdx.x * 256 + threadIdx.x] = t.x + t.y;
+}
+template <int OP> void runpk(float* d, const char* name, float t_fma) {
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  float best = 1e9;
+  for (int rep = 0; rep < 5; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(kpk<OP>, dim3(8192), dim3(256), 0, 0, d, 1.0001f, 0.5f, 300);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  printf("{\"op\": \"%s\", \"ms\": %.4f, \"instructions_per_slot\": 1, \"time_over_fma_stream\": %.3f, \"cycles_per_slot_at_2_per_fma\": %.2f, \"note\": \"two fp32 operations per lane and instruction\"}\n",
+         name, best, best / t_fma, 2.0 * best / t_fma);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, float a, float b, int iters) {
   __shared__ float lds[1024];
@@ -106,5 +141,6 @@ int main() {
   run<22>(d, "v_fma_f32 + s_and_b64 + s_or_b64", 3, "slot = 1 VALU + 2 SALU");
   run<23>(d, "v_fma_f32 + s_nop 1", 2, "the DPP hazard fences of the reduction");
   run<24>(d, "v_cmp_e64 + s_and_b64 + v_cndmask_e64", 3, "one mask ladder of the blend (compare -> combine -> select)");
+  runpk<0>(d, "v_pk_fma_f32", t_fma); runpk<1>(d, "v_pk_mul_f32", t_fma); runpk<2>(d, "v_pk_add_f32", t_fma);
   return 0;
 }
