@@ -2,7 +2,7 @@
 times) against the CPU oracle chained through the reference's activations and loss, fp32 and fp64, under the one parity rule
 (tests/arbiter.py::assert_parity).  The GPU tests sample 1 - 3 (item, view) pairs per scene-level config because the oracle needs minutes for a
 whole batch there; this tool spends them once per round and its log is committed (profiles/r06/whole_batch_parity.log).
-usage: python tools/whole_batch_parity.py C4 [C5 ...]"""
+usage: python tools/whole_batch_parity.py C4 [C5 ...]      (U3D_WBP_SEED=<n>: another draw of the synthetic batch; default 42)"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -17,7 +17,7 @@ for name in sys.argv[1:] or ["C4"]:
     cfg = synthetic.CONFIGS[name]
     B, P, V, H, W, level = cfg["B"], cfg["P"], cfg["V"], cfg["H"], cfg["W"], cfg["level"]
     kind = "focal_l2" if level == "object" else "l2"
-    b = synthetic.make_batch(B, P, V, H, W, level=level, seed=42)
+    b = synthetic.make_batch(B, P, V, H, W, level=level, seed=int(os.environ.get("U3D_WBP_SEED", "42")))
     bd = b.to(dev)
     h = bd.raw.permute(0, 2, 1).contiguous().requires_grad_(True)
     loss, _, _ = fused.render_loss_fused(h, bd.center, bd.world_view, bd.full_proj, bd.camera_center, bd.gt, bd.bg, bd.fov_deg, H, W, level=level,
