@@ -612,8 +612,8 @@ __device__ __forceinline__ void store4(float* __restrict__ p, bool vec, const bo
 // (6 waves per SIMD).  The single-pass kernel is PINNED: round 4 measured 8 waves per SIMD (64 VGPRs, a handful of values spilled around the rarely
 // taken variant) 3 % ahead of the unpinned build; with round 5's alpha_run and round 6's forward the optimum moved to 7 (72 VGPRs, fewer spills):
 // render_fb scope, pins 8 / 7 / 6 / none on one box, two rounds: C2 176.0 / 173.2 - 173.7 / 176.1 - 176.3 / 177.2 - 177.5 us, C3 91.8 - 92.4 / 90.5 - 91.0 /
-// 92.1 - 92.2 / 92.3, C5 103.3 - 103.8 / 101.4 - 101.5 / 100.7 - 101.0 / 101.0 - 101.5.  The two-pass kernels measured slower pinned (forward 97 against
-// 87 us at C2) and are left to the allocator.
+// 92.1 - 92.2 / 92.3, C5 103.3 - 103.8 / 101.4 - 101.5 / 100.7 - 101.0 / 101.0 - 101.5.  The two-pass kernels measured slower pinned to 8 (forward 97 against
+// 87 us at C2); the forward is left to the allocator (61 / 66 VGPRs), the backward's object-level instantiation takes 7 (see U3D_BWD_OCC_PIN).
 #ifdef U3D_NO_OCC_PIN   /* tools/pmc_spill_probe.sh: the unpinned build, to attribute the scratch-spill share of the kernel's HBM writes */
 #define U3D_FULL_OCCUPANCY
 #else
@@ -719,8 +719,19 @@ __global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_fwd_wave_kernel(
 }
 
 // ---- backward (operator path, and second pass of the two-pass fused loss) ------------------------------------
+// Occupancy: the allocator gives this kernel 76 VGPRs = 6 waves per SIMD.  Round 6: the object-level instantiation without inverse-depth gradients (PB == 1, !HAS_INVD: what the reference's call produces) is pinned to 7 (72 VGPRs,
+// 20 B of scratch per lane) like the single-pass kernel: two-pass route, render_bwd 161.0 -> 156.2 us at C2 in two alternating pairs; the scene-level
+// one (PB == 2) measured -0.8 % at C3 but +1.6 % at C5 pinned and is left to the allocator (1 .. 10 = no constraint).  U3D_BWD_OCC_PIN=0: no pin at all.
+#ifndef U3D_BWD_OCC_PIN
+#define U3D_BWD_OCC_PIN 7
+#endif
+#if U3D_BWD_OCC_PIN
+#define U3D_BWD_OCCUPANCY __attribute__((amdgpu_waves_per_eu((PB == 1 && !HAS_INVD) ? U3D_BWD_OCC_PIN : 1, (PB == 1 && !HAS_INVD) ? U3D_BWD_OCC_PIN : 10)))
+#else
+#define U3D_BWD_OCCUPANCY
+#endif
 template <bool HAS_INVD, int PB>
-__global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) void render_bwd_wave_kernel(
+__global__ __launch_bounds__(TILE_WAVES * U3D_WAVE) U3D_BWD_OCCUPANCY void render_bwd_wave_kernel(
     U3DSpan span, int H, int W, int tiles_x, int T, uint32_t ntiles_total, uint32_t tile_magic, size_t NG,
     const uint32_t* __restrict__ sorted_id, const uint2* __restrict__ sorted_rect, int rect_indirect, const float2* __restrict__ xy,
     const float4* __restrict__ conic_op, const float4* __restrict__ rgbd, const float* __restrict__ bg,
